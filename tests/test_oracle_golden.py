@@ -1,0 +1,147 @@
+"""Pins oracle/zedo_oracle.py (numpy restatement) against golden vectors captured from the
+reference itself (tools/gen_golden.py).  CPU only.
+
+Tolerances: single calls agree to fp32 round-off.  The 1000-step OIL loop and the 500-step
+IPO loop are numerically expansive with random weights: the
+reference run in fp32 and in fp64 drifts apart by up to 1.6e-3 m, so long-loop snapshots are
+bounded by that self-gap, not by round-off.
+"""
+import numpy as np
+import pytest
+
+import zedo_oracle as O
+from lib.dataset import synthetic as syn
+
+
+def test_weights_generator_is_pinned(golden, weights0):
+    g = golden("model_forward")
+    assert str(g["weights_sha"]) == syn.weights_checksum(weights0)
+    assert [k for k in weights0] == [n for n, _ in syn.state_dict_layout()]
+    assert sum(v.size for v in weights0.values()) == 7203379 - 0  # 34 tensors, reference count
+
+
+def test_score_network_forward(golden, weights0):
+    g = golden("model_forward")
+    for i, t in enumerate(g["ts"]):
+        eps = O.score_model_forward(weights0, g["x"], np.float32(t) * np.float32(999))
+        np.testing.assert_allclose(eps, g["eps"][i], atol=1e-6, rtol=0)
+    tb = O.time_bias_table(weights0, g["ts"] * np.float32(999))
+    np.testing.assert_allclose(tb, g["tbias"], atol=3e-6, rtol=0)
+    te = O.time_embed(weights0, g["ts"] * np.float32(999))
+    np.testing.assert_allclose(te, g["temb"], atol=3e-6, rtol=0)
+    # sin/cos of arguments up to ~100 rad: one ulp of the fp32 frequency moves the result by ~1e-5
+    pe = O.timestep_embedding(g["pe_labels"], 512)[::37]
+    np.testing.assert_allclose(pe, g["pe"], atol=5e-5, rtol=0)
+
+
+@pytest.mark.parametrize("S", [1000, 100])
+def test_pc_step_and_schedule(golden, weights0, S):
+    p = golden("pc_step")
+    ts = O.oil_timestamps(S)
+    assert np.array_equal(ts, p[f"ts_{S}"])           # torch.linspace, bit for bit
+    a, c = O.step_coeffs(p[f"ts_{S}"].astype(np.float64))
+    for k, i in enumerate(p[f"idx_{S}"]):
+        xm = O.pc_step(weights0, p["x"], p[f"ts_{S}"][i])
+        np.testing.assert_allclose(xm, p[f"xmean_{S}"][k], atol=2e-7, rtol=0)
+        eps = O.score_model_forward(weights0, p["x"], p[f"ts_{S}"][i] * np.float32(999))
+        closed = np.float32(a[i]) * p["x"] + np.float32(c[i]) * eps
+        np.testing.assert_allclose(closed, p[f"xmean_{S}"][k], atol=3e-7, rtol=0)
+    if S == 1000:  # SURVEY 3.2 worked values
+        assert abs(c[0] - (-3.963e-3)) < 2e-6 and abs(c[-1] - (-5.974e-4)) < 2e-7
+
+
+def test_score_fn(golden, weights0):
+    p = golden("pc_step")
+    np.testing.assert_allclose(O.score_fn(weights0, p["x"], 0.05), p["score_t0p05"], atol=2e-5, rtol=0)
+
+
+def test_gradient_field_gen(golden):
+    r = golden("reproj")
+    ones = np.ones((16, 17), np.float32)
+    for tag, conf in (("wild", r["conf_wild"]), ("ones", ones), ("none", None)):
+        g1, T1 = O.gradient_field_gen(r["uv"], r["x"], r["K"], t=r["T_given"], conf=conf)
+        np.testing.assert_allclose(g1, r[f"g_given_{tag}"], atol=1e-6, rtol=0)
+        assert np.array_equal(T1, r["T_given"])
+        g2, T2 = O.gradient_field_gen(r["uv"], r["x"], r["K"], t=None, conf=conf)
+        np.testing.assert_allclose(g2, r[f"g_solve_{tag}"], atol=3e-6, rtol=0)
+        np.testing.assert_allclose(T2, r[f"T_solve_{tag}"], atol=1e-5, rtol=0)
+    assert np.array_equal(O.clamp_conf(r["conf_wild"]), r["conf_after_wild"])
+    assert r["conf_after_wild"].max() == 1.0 and r["conf_after_wild"].min() == np.float32(1e-4)
+    # sign fix: mirrored detections give a negative least-squares depth that is negated
+    g, T = O.gradient_field_gen(r["uv_neg"], r["x_rel"], r["K"], conf=ones)
+    assert (r["T_neg"][:, 0, 2] > 4).all()
+    np.testing.assert_allclose(T, r["T_neg"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(g, r["g_neg"], atol=3e-6, rtol=0)
+    g, T = O.gradient_field_gen(r["uv"], r["x_far"], r["K"], conf=ones)
+    np.testing.assert_allclose(T, r["T_far"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(g, r["g_far"], atol=2e-5, rtol=0)
+
+
+IPO_CASES = [(N, axes, kname) for N in (8, 64) for axes in ("z", "xyz") for kname in ("h36m", "pw3d")]
+
+
+@pytest.mark.parametrize("N,axes,kname", IPO_CASES)
+def test_ipo_hand_derived_gradients_follow_autograd(golden, N, axes, kname):
+    g = golden("ipo")
+    kl, ipoT, minT = ([0, 1, 4], 3.0, 0.5) if kname == "h36m" else (list(range(17)), 8.0, 0.2)
+    tag = f"{N}_{axes}_{kname}"
+    cond, K = g[f"db2d_{N}"][:, :, :2], g[f"K_{N}"]
+    x0 = np.broadcast_to(g["cluster0"][None], (N, 17, 3)).astype(np.float32)
+    T0 = O.ipo_init_T(cond, K, ipoT)
+    np.testing.assert_allclose(T0, g[f"T0_{tag}"], atol=1e-6, rtol=0)
+    tr = []
+    R, T, q, s, loss = O.ipo_fit(x0[:, kl], T0, K, cond[:, kl], axes, minT, 2.0, 500, trace=tr)
+    # Adam on an L1 loss is chaotic: parity is per-iteration at the start, distributional at the end
+    for it, tol in ((0, 1e-6), (4, 1e-5), (19, 1e-3)):
+        np.testing.assert_allclose(tr[it][0], g[f"trace_q_{tag}"][it], atol=tol, rtol=0)
+        np.testing.assert_allclose(tr[it][1], g[f"trace_scale_{tag}"][it], atol=tol, rtol=0)
+        assert abs(tr[it][2] - g[f"trace_loss_{tag}"][it]) <= 1e-4 * max(1.0, g[f"trace_loss_{tag}"][it])
+    assert abs(loss - g[f"loss_{tag}"]) <= 0.05 * g[f"loss_{tag}"]
+    assert np.allclose(np.einsum("bij,bkj->bik", R, R), np.eye(3)[None], atol=1e-5)
+
+
+@pytest.mark.parametrize("S", [100, 1000])
+def test_oil_loop_snapshots(golden, weights0, S):
+    g = golden("oil")
+    steps = g[f"snap_steps_{S}"]
+    sn = {int(s): None for s in steps}
+    x, T = O.oil_loop(weights0, g["x_init"], g["db2d"][:, :, :2], g["K"], g["db2d"][:, :, 2], g["T_init"], S,
+                      snapshots=sn)
+    self_gap = np.abs(g[f"snaps_{S}_f32"] - g[f"snaps_{S}_f64"]).reshape(len(steps), -1).max(1)
+    for i, s in enumerate(steps):
+        d = np.abs(sn[int(s)] - g[f"snaps_{S}_f32"][i]).max()
+        if s <= S // 5:            # fixed-T phase: contractive, round-off level
+            assert d <= 1e-5, (s, d)
+        assert d <= max(1e-5, self_gap[i]), (s, d, self_gap[i])
+
+
+def test_eval_multi_and_procrustes(golden):
+    g = golden("eval_multi")
+    gt = (g["gt_mm_h36m"] - g["gt_mm_h36m"][:, 0:1]) / 1000.0
+    np.testing.assert_allclose(O.hypothesis_errors(g["preds"], gt, False), g["err_p1"], atol=1e-12, rtol=0)
+    np.testing.assert_allclose(O.hypothesis_errors(g["preds"], gt, True), g["err_p2"], atol=2e-7, rtol=0)
+    Z = O.procrustes_align(np.broadcast_to(gt[:, None], g["preds"].shape), g["preds"])
+    np.testing.assert_allclose(Z, g["aligned"], atol=5e-7, rtol=0)
+    for p2, key in ((False, "p1"), (True, "p2")):
+        v, best, idx = O.eval_multi(g["preds"], gt, p2, actions=g["actions"])
+        assert abs(v - float(g["h36m_" + key])) < 1e-7
+        ref = g["err_" + key]
+        assert np.array_equal(idx, ref.argmin(1))
+        gp = g["db3d_pw3d"] - g["db3d_pw3d"][:, 0:1]
+        v, _, _ = O.eval_multi(g["preds"], gp, p2)
+        assert abs(v - float(g["pw3d_" + key])) < 1e-7
+    # the mirrored hypotheses must have been aligned with a reflection (det < 0 allowed by 'best')
+    assert (g["err_p2"][::4, 3] < 1e-6).all()
+
+
+def test_driver_config1_end_to_end(golden, weights0):
+    """BASELINE config 1 (N=64, H=1, S=100): dataset-mean MPJPE / PA-MPJPE within 0.05 mm."""
+    d = golden("driver_cfg1")
+    cfg = dict(IPO_iterations=500, IPO_keylist=[0, 1, 4], RotAxes="z", IPO_T=3, IPO_minScaleT=0.5,
+               IPO_maxScaleT=2, OIL_iterations=100, sampling_eps=0.01, sde_T=0.1, num_scales=1000,
+               beta_min=0.1, beta_max=20.0)
+    res = O.zedo_pipeline(weights0, d["clusters"], d["db_2d"], d["K"], cfg)
+    assert res.shape == d["batch_results"].shape == (64, 1, 17, 3)
+    gt = d["db_3d"] - d["db_3d"][:, 0:1]
+    assert abs(O.eval_multi(res, gt)[0] - float(d["mpjpe"])) < 5e-5
+    assert abs(O.eval_multi(res, gt, True)[0] - float(d["pa_mpjpe"])) < 5e-5
