@@ -1,0 +1,423 @@
+// C ABI of libzedo_hip.so (declared in include/zedo_hip.h): handle management, table building and the
+// launch sequences of the ZeDO hot path on gfx950.  No global state besides the opaque handles.
+#include "../../include/zedo_hip.h"
+#include "zedo_internal.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace zedo;
+
+struct zedo_weights {
+    int J3, hidden, embed, n_blocks;
+    float *d_all;           // one allocation holding everything below
+    const float *W_pre;     // [H][XLD]   pre_dense.weight, K zero-padded 51 -> 64
+    const float *W_hid[4];  // [H][H]     b{1,2}_dense{1,2}.weight
+    const float *W_post;    // [XLD][H]   post_dense.weight, rows zero-padded 51 -> 64
+    const float *b_post;    // [XLD]
+    const float *gamma[NLAYER], *beta[NLAYER];
+    const float *W_s, *b_s;         // shared_time_embed.0
+    const float *W_t[NLAYER];       // [H][E]  *_t.weight
+    const float *b_sum[NLAYER];     // [H]     *_t.bias + dense.bias (both row-invariant)
+};
+
+struct zedo_schedule {
+    int S, Sp, nl, hidden;
+    float *d_tbias;  // [Sp][NLAYER][H]
+    std::vector<float> a, c;
+};
+
+#define HIPCHK(x)                      \
+    do {                               \
+        hipError_t e_ = (x);           \
+        if (e_ != hipSuccess) return (int)e_; \
+    } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- optional sampled kernel timing (diagnostics for bench.py's roofline object) ------------------
+// Every `every`-th launch of a kernel class is bracketed by two hipEvents recorded on the launch stream
+// itself, so the elapsed time is that kernel's duration as the stream saw it.  Off by default.
+namespace {
+struct Prof {
+    bool on = false;
+    int every = 1;
+    struct Pair { hipEvent_t a, b; int cls; };
+    std::vector<Pair> pool;
+    size_t used = 0;
+    long long seen[ZEDO_PROF_CLASSES] = {0, 0, 0, 0};
+} g_prof;
+
+struct ProfScope {
+    Prof::Pair *pr = nullptr;
+    hipStream_t st;
+    ProfScope(int cls, hipStream_t s) : st(s) {
+        if (!g_prof.on) return;
+        if ((g_prof.seen[cls]++ % g_prof.every) != 0 || g_prof.used >= g_prof.pool.size()) return;
+        pr = &g_prof.pool[g_prof.used++];
+        pr->cls = cls;
+        (void)hipEventRecord(pr->a, st);
+    }
+    ~ProfScope() { if (pr) (void)hipEventRecord(pr->b, st); }
+};
+}  // namespace
+
+extern "C" int zedo_profile_start(int sample_every, int max_samples) {
+    if (sample_every < 1 || max_samples < 1) return ZEDO_E_BADARG;
+    if (g_prof.pool.size() < (size_t)max_samples) {
+        size_t old = g_prof.pool.size();
+        g_prof.pool.resize(max_samples);
+        for (size_t i = old; i < g_prof.pool.size(); ++i) {
+            HIPCHK(hipEventCreate(&g_prof.pool[i].a));
+            HIPCHK(hipEventCreate(&g_prof.pool[i].b));
+        }
+    }
+    g_prof.used = 0;
+    for (auto &v : g_prof.seen) v = 0;
+    g_prof.every = sample_every;
+    g_prof.on = true;
+    return ZEDO_OK;
+}
+
+extern "C" int zedo_profile_stop(double *h_total_ms, long long *h_samples, long long *h_launches) {
+    g_prof.on = false;
+    double tot[ZEDO_PROF_CLASSES] = {0, 0, 0, 0};
+    long long cnt[ZEDO_PROF_CLASSES] = {0, 0, 0, 0};
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        HIPCHK(hipEventSynchronize(g_prof.pool[i].b));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, g_prof.pool[i].a, g_prof.pool[i].b));
+        tot[g_prof.pool[i].cls] += ms;
+        cnt[g_prof.pool[i].cls] += 1;
+    }
+    for (int c = 0; c < ZEDO_PROF_CLASSES; ++c) {
+        if (h_total_ms) h_total_ms[c] = tot[c];
+        if (h_samples) h_samples[c] = cnt[c];
+        if (h_launches) h_launches[c] = g_prof.seen[c];
+    }
+    g_prof.used = 0;
+    return ZEDO_OK;
+}
+
+static size_t chunk_rows_cap() {
+    static size_t cap = 0;
+    if (!cap) {
+        const char *e = getenv("ZEDO_CHUNK_ROWS");
+        long v = e ? atol(e) : 0;
+        cap = v > 0 ? (size_t)round_up((int)v, ROW_PAD) : (size_t)1 << 20;
+    }
+    return cap;
+}
+
+extern "C" int zedo_abi_version(void) { return ZEDO_ABI_VERSION; }
+
+extern "C" const char *zedo_error_string(int code) {
+    switch (code) {
+        case ZEDO_OK: return "ok";
+        case ZEDO_E_BADARG: return "zedo: bad argument (null pointer, size, or unsupported dimension)";
+        case ZEDO_E_NOGPU: return "zedo: no gfx950 device";
+        case ZEDO_E_WORKSPACE: return "zedo: workspace too small";
+    }
+    return code > 0 ? hipGetErrorString((hipError_t)code) : "zedo: unknown error";
+}
+
+static int check_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return ZEDO_E_NOGPU;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return ZEDO_E_NOGPU;
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) return ZEDO_E_NOGPU;
+    return ZEDO_OK;
+}
+
+extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n_joints, int joint_dim, int hidden,
+                                   int embed, int n_blocks, void *stream, zedo_weights_t **out) {
+    if (!h_params || !out) return ZEDO_E_BADARG;
+    const int J3 = n_joints * joint_dim;
+    if (hidden != HID || embed != EMB || n_blocks != 2 || J3 < 1 || J3 > XLD) return ZEDO_E_BADARG;
+    const size_t H = hidden, E = embed;
+    const size_t expect = (H * J3 + H) + (H * E + H) + 2 * H + (E * E + E) + 4 * ((H * H + H) + (H * E + H) + 2 * H) +
+                          ((size_t)J3 * H + J3);
+    if (n_floats != expect) return ZEDO_E_BADARG;
+    if (int rc = check_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+
+    // device layout (floats)
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
+    const size_t o_Wpre = take(H * XLD), o_Whid0 = take(4 * H * H), o_Wpost = take((size_t)XLD * H), o_bpost = take(XLD);
+    const size_t o_gamma = take(NLAYER * H), o_beta = take(NLAYER * H), o_Ws = take(E * E), o_bs = take(E);
+    const size_t o_Wt = take(NLAYER * H * E), o_bsum = take(NLAYER * H);
+    std::vector<float> img(off, 0.0f);
+
+    const float *p = h_params;
+    auto next = [&](size_t n) { const float *q = p; p += n; return q; };
+    // pre_dense
+    const float *w_pre = next(H * J3), *b_pre = next(H), *w_pre_t = next(H * E), *b_pre_t = next(H);
+    const float *g_pre = next(H), *be_pre = next(H);
+    const float *w_s = next(E * E), *b_s = next(E);
+    for (size_t n = 0; n < H; ++n) memcpy(&img[o_Wpre + n * XLD], w_pre + n * J3, sizeof(float) * J3);
+    memcpy(&img[o_gamma], g_pre, sizeof(float) * H);
+    memcpy(&img[o_beta], be_pre, sizeof(float) * H);
+    memcpy(&img[o_Ws], w_s, sizeof(float) * E * E);
+    memcpy(&img[o_bs], b_s, sizeof(float) * E);
+    memcpy(&img[o_Wt], w_pre_t, sizeof(float) * H * E);
+    for (size_t n = 0; n < H; ++n) img[o_bsum + n] = b_pre_t[n] + b_pre[n];
+    for (int l = 1; l < NLAYER; ++l) {
+        const float *w = next(H * H), *b = next(H), *wt = next(H * E), *bt = next(H), *g = next(H), *be = next(H);
+        memcpy(&img[o_Whid0 + (size_t)(l - 1) * H * H], w, sizeof(float) * H * H);
+        memcpy(&img[o_Wt + (size_t)l * H * E], wt, sizeof(float) * H * E);
+        memcpy(&img[o_gamma + (size_t)l * H], g, sizeof(float) * H);
+        memcpy(&img[o_beta + (size_t)l * H], be, sizeof(float) * H);
+        // h += dense(x); h += dense_t(temb): (acc + b) + (acc_t + b_t).  Summing the two biases first
+        // changes only the rounding order of a row-invariant constant.
+        for (size_t n = 0; n < H; ++n) img[o_bsum + (size_t)l * H + n] = bt[n] + b[n];
+    }
+    const float *w_post = next((size_t)J3 * H), *b_post = next(J3);
+    memcpy(&img[o_Wpost], w_post, sizeof(float) * J3 * H);
+    memcpy(&img[o_bpost], b_post, sizeof(float) * J3);
+
+    zedo_weights *w = new (std::nothrow) zedo_weights();
+    if (!w) return (int)hipErrorOutOfMemory;
+    w->J3 = J3; w->hidden = hidden; w->embed = embed; w->n_blocks = n_blocks;
+    hipError_t e = hipMalloc(&w->d_all, off * sizeof(float));
+    if (e != hipSuccess) { delete w; return (int)e; }
+    e = hipMemcpyAsync(w->d_all, img.data(), off * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(w->d_all); delete w; return (int)e; }
+    const float *d = w->d_all;
+    w->W_pre = d + o_Wpre;
+    for (int l = 0; l < 4; ++l) w->W_hid[l] = d + o_Whid0 + (size_t)l * H * H;
+    w->W_post = d + o_Wpost; w->b_post = d + o_bpost;
+    for (int l = 0; l < NLAYER; ++l) {
+        w->gamma[l] = d + o_gamma + (size_t)l * H; w->beta[l] = d + o_beta + (size_t)l * H;
+        w->W_t[l] = d + o_Wt + (size_t)l * H * E;  w->b_sum[l] = d + o_bsum + (size_t)l * H;
+    }
+    w->W_s = d + o_Ws; w->b_s = d + o_bs;
+    *out = w;
+    return ZEDO_OK;
+}
+
+extern "C" void zedo_weights_destroy(zedo_weights_t *w) {
+    if (!w) return;
+    (void)hipFree(w->d_all);
+    delete w;
+}
+
+extern "C" int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, int S, float beta_min, float beta_max,
+                                    int n_sde, void *stream, zedo_schedule_t **out) {
+    if (!w || !h_t || !out || S < 1 || n_sde < 1) return ZEDO_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int Sp = round_up(S, ROW_PAD);
+    zedo_schedule *s = new (std::nothrow) zedo_schedule();
+    if (!s) return (int)hipErrorOutOfMemory;
+    s->S = S; s->Sp = Sp; s->nl = NLAYER; s->hidden = HID;
+    s->a.resize(S); s->c.resize(S);
+    // x' = x + drift*dt, drift = -beta/2 x - beta*disc*score, score = -eps/std, dt = -1/n_sde
+    //   => a = 1 + beta/(2 n_sde),  c = -beta*disc/(n_sde*std)      (sde_lib.py:187-198, sampling.py:185-190)
+    for (int i = 0; i < S; ++i) {
+        const double t = (double)h_t[i], b0 = (double)beta_min, b1 = (double)beta_max;
+        const double beta = b0 + t * (b1 - b0);
+        const double disc = 1.0 - std::exp(-2.0 * b0 * t - (b1 - b0) * t * t);
+        const double sd = 1.0 - std::exp(2.0 * (-0.25 * t * t * (b1 - b0) - 0.5 * t * b0));
+        s->a[i] = (float)(1.0 + 0.5 * beta / n_sde);
+        s->c[i] = (float)(-(beta * disc) / (n_sde * sd));
+    }
+    float *d_t = nullptr, *d_pe = nullptr, *d_temb = nullptr;
+    s->d_tbias = nullptr;
+    hipError_t e = hipMalloc(&d_t, sizeof(float) * S);
+    if (e == hipSuccess) e = hipMalloc(&d_pe, sizeof(float) * (size_t)Sp * EMB);
+    if (e == hipSuccess) e = hipMalloc(&d_temb, sizeof(float) * (size_t)Sp * EMB);
+    if (e == hipSuccess) e = hipMalloc(&s->d_tbias, sizeof(float) * (size_t)Sp * NLAYER * HID);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_t, h_t, sizeof(float) * S, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = launch_posemb(d_t, S, Sp, d_pe, st);
+    if (e == hipSuccess) {
+        // temb = SiLU(W_s pe + b_s)   (model.py:128-131,259)
+        LayerArgs a{};
+        a.X = d_pe; a.ldx = EMB; a.W = w->W_s; a.ldw = EMB; a.bias = w->b_s; a.out = d_temb; a.ldo = EMB;
+        a.K = EMB; a.N = EMB; a.Mp = Sp;
+        e = launch_layer(a, EPI_BIAS_SILU, st);
+    }
+    for (int l = 0; l < NLAYER && e == hipSuccess; ++l) {
+        LayerArgs a{};
+        a.X = d_temb; a.ldx = EMB; a.W = w->W_t[l]; a.ldw = EMB; a.bias = w->b_sum[l];
+        a.out = s->d_tbias + (size_t)l * HID; a.ldo = NLAYER * HID; a.K = EMB; a.N = HID; a.Mp = Sp;
+        e = launch_layer(a, EPI_BIAS, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_t); (void)hipFree(d_pe); (void)hipFree(d_temb);
+    if (e != hipSuccess) { (void)hipFree(s->d_tbias); delete s; return (int)e; }
+    *out = s;
+    return ZEDO_OK;
+}
+
+extern "C" void zedo_schedule_destroy(zedo_schedule_t *s) {
+    if (!s) return;
+    (void)hipFree(s->d_tbias);
+    delete s;
+}
+
+extern "C" int zedo_schedule_read(const zedo_schedule_t *s, float *h_tbias, float *h_a, float *h_c) {
+    if (!s) return ZEDO_E_BADARG;
+    if (h_tbias) HIPCHK(hipMemcpy(h_tbias, s->d_tbias, sizeof(float) * (size_t)s->S * NLAYER * HID, hipMemcpyDeviceToHost));
+    if (h_a) memcpy(h_a, s->a.data(), sizeof(float) * s->S);
+    if (h_c) memcpy(h_c, s->c.data(), sizeof(float) * s->S);
+    return ZEDO_OK;
+}
+
+static inline size_t ws_rows(int B) { return (size_t)round_up((int)std::min((size_t)B, chunk_rows_cap()), ROW_PAD); }
+
+extern "C" size_t zedo_workspace_bytes(int B) {
+    if (B < 1) return 0;
+    return ws_rows(B) * (size_t)(XLD + 2 * HID) * sizeof(float);
+}
+
+extern "C" int zedo_reproj_prepare(const float *d_uv, const float *d_K, const float *d_conf, int N, int J, float *d_geom,
+                                   float *d_conf_clamped, void *stream) {
+    if (!d_uv || !d_K || !d_geom || N < 1 || J < 1) return ZEDO_E_BADARG;
+    HIPCHK(launch_reproj_prepare(d_uv, d_K, d_conf, N, J, d_geom, d_conf_clamped, (hipStream_t)stream));
+    return ZEDO_OK;
+}
+
+extern "C" int zedo_reproj_grad(const float *d_x, const float *d_geom, float *d_T, int solve_T, float *d_g, int B, int N,
+                                int J, long long row_offset, void *stream) {
+    if (!d_x || !d_geom || !d_T || !d_g || B < 1 || N < 1 || J != 17 || row_offset < 0) return ZEDO_E_BADARG;
+    HIPCHK(launch_reproj_grad(d_x, d_geom, d_T, solve_T, d_g, B, N, J, row_offset, (hipStream_t)stream));
+    return ZEDO_OK;
+}
+
+// The six dense layers of one score-network evaluation on Bp padded rows (model.py:264-291), ending either in
+// eps -> xpad (EPI_BIAS, for zedo_score_eps) or in the SDE update of xpad (EPI_SDE).
+static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad, float *h, float *h1, int Bp, bool sde,
+                             float sa, float sc, float *eps_out, hipStream_t st) {
+    LayerArgs a{};
+    a.Mp = Bp;
+    // pre_dense + pre_gnorm + SiLU
+    a.X = xpad; a.ldx = XLD; a.W = w->W_pre; a.ldw = XLD; a.K = XLD; a.N = HID;
+    a.bias = tb; a.gamma = w->gamma[0]; a.beta = w->beta[0]; a.out = h; a.ldo = HID;
+    hipError_t e;
+    { ProfScope ps(ZEDO_PROF_PRE, st); e = launch_layer(a, EPI_GN_SILU, st); }
+    for (int blk = 0; blk < 2 && e == hipSuccess; ++blk) {
+        const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
+        a.X = h; a.ldx = HID; a.W = w->W_hid[l1 - 1]; a.ldw = HID; a.K = HID; a.N = HID;
+        a.bias = tb + (size_t)l1 * HID; a.gamma = w->gamma[l1]; a.beta = w->beta[l1]; a.out = h1; a.ldo = HID;
+        { ProfScope ps(ZEDO_PROF_HIDDEN, st); e = launch_layer(a, EPI_GN_SILU, st); }
+        if (e != hipSuccess) break;
+        a.X = h1; a.W = w->W_hid[l2 - 1];
+        a.bias = tb + (size_t)l2 * HID; a.gamma = w->gamma[l2]; a.beta = w->beta[l2]; a.out = h;  // h = h + h2, in place
+        { ProfScope ps(ZEDO_PROF_HIDDEN, st); e = launch_layer(a, EPI_GN_SILU_RES, st); }
+    }
+    if (e != hipSuccess) return e;
+    a.X = h; a.ldx = HID; a.W = w->W_post; a.ldw = HID; a.K = HID; a.N = XLD; a.bias = w->b_post;
+    a.gamma = a.beta = nullptr; a.ldo = XLD;
+    ProfScope ps(ZEDO_PROF_POST, st);
+    if (sde) { a.out = xpad; a.sde_a = sa; a.sde_c = sc; return launch_layer(a, EPI_SDE, st); }
+    a.out = eps_out;
+    return launch_layer(a, EPI_BIAS, st);
+}
+
+struct Ws { float *xpad, *h, *h1; size_t rows; };
+static Ws carve(void *ws, int B) {
+    Ws r; r.rows = ws_rows(B);
+    r.xpad = (float *)ws; r.h = r.xpad + r.rows * XLD; r.h1 = r.h + r.rows * HID;
+    return r;
+}
+
+static int step_common(const zedo_weights_t *w, const zedo_schedule_t *s, int step, const float *d_x_in, float *d_out,
+                       bool sde, int B, void *ws, size_t ws_bytes, hipStream_t st) {
+    if (!w || !s || !d_x_in || !d_out || !ws || B < 1 || step < 0 || step >= s->S) return ZEDO_E_BADARG;
+    if (ws_bytes < zedo_workspace_bytes(B)) return ZEDO_E_WORKSPACE;
+    const size_t cap = chunk_rows_cap();
+    const float *tb = s->d_tbias + (size_t)step * NLAYER * HID;
+    for (size_t r0 = 0; r0 < (size_t)B; r0 += cap) {
+        const int Bc = (int)std::min(cap, (size_t)B - r0), Bp = round_up(Bc, ROW_PAD);
+        Ws k = carve(ws, B);
+        HIPCHK(launch_pack_rows(d_x_in + r0 * w->J3, k.xpad, Bc, Bp, w->J3, st));
+        if (sde) {
+            HIPCHK(mlp_layers(w, tb, k.xpad, k.h, k.h1, Bp, true, s->a[step], s->c[step], nullptr, st));
+            HIPCHK(launch_unpack_rows(k.xpad, d_out + r0 * w->J3, Bc, w->J3, st));
+        } else {
+            // eps lands in h1's first XLD columns region: reuse h1 as [Bp][XLD]
+            HIPCHK(mlp_layers(w, tb, k.xpad, k.h, k.h1, Bp, false, 0.f, 0.f, k.h1, st));
+            HIPCHK(launch_unpack_rows(k.h1, d_out + r0 * w->J3, Bc, w->J3, st));
+        }
+    }
+    return ZEDO_OK;
+}
+
+extern "C" int zedo_score_eps(const zedo_weights_t *w, const zedo_schedule_t *s, int step, const float *d_x, float *d_eps,
+                              int B, void *d_workspace, size_t workspace_bytes, void *stream) {
+    return step_common(w, s, step, d_x, d_eps, false, B, d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int zedo_sde_step(const zedo_weights_t *w, const zedo_schedule_t *s, int step, float *d_x, int B,
+                             void *d_workspace, size_t workspace_bytes, void *stream) {
+    return step_common(w, s, step, d_x, d_x, true, B, d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int zedo_oil_run(const zedo_weights_t *w, const zedo_schedule_t *s, float *d_x, const float *d_geom, float *d_T,
+                            int step_begin, int step_end, int switch_step, int B, int N, long long row_offset,
+                            void *d_workspace, size_t workspace_bytes, void *stream) {
+    if (!w || !s || !d_x || !d_geom || !d_T || !d_workspace || B < 1 || N < 1 || row_offset < 0) return ZEDO_E_BADARG;
+    if (step_begin < 0 || step_end > s->S || step_begin > step_end || w->J3 != 51) return ZEDO_E_BADARG;
+    if (workspace_bytes < zedo_workspace_bytes(B)) return ZEDO_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t cap = chunk_rows_cap();
+    for (size_t r0 = 0; r0 < (size_t)B; r0 += cap) {
+        const int Bc = (int)std::min(cap, (size_t)B - r0), Bp = round_up(Bc, ROW_PAD);
+        Ws k = carve(d_workspace, B);
+        HIPCHK(launch_pack_rows(d_x + r0 * w->J3, k.xpad, Bc, Bp, w->J3, st));
+        for (int i = step_begin; i < step_end; ++i) {
+            // gradient_field_gen + "denoise_x += joint_gradient" (run/opt_main.py:203-208)
+            {
+                ProfScope ps(ZEDO_PROF_REPROJ, st);
+                HIPCHK(launch_reproj_step_padded(k.xpad, d_geom, d_T + r0 * 3, i >= switch_step, Bc, N,
+                                                 row_offset + (long long)r0, st));
+            }
+            // sampling_fn(...) (run/opt_main.py:210-218) -> x = a_i x + c_i eps(x, t_i)
+            HIPCHK(mlp_layers(w, s->d_tbias + (size_t)i * NLAYER * HID, k.xpad, k.h, k.h1, Bp, true, s->a[i], s->c[i],
+                              nullptr, st));
+        }
+        HIPCHK(launch_unpack_rows(k.xpad, d_x + r0 * w->J3, Bc, w->J3, st));
+    }
+    return ZEDO_OK;
+}
+
+extern "C" int zedo_ipo_fit(const float *d_x0, const float *d_uv, const float *d_K, const int *h_keylist, int k,
+                            int axes_mask, float ipo_T, float min_scale, float max_scale, int iters, double normaliser,
+                            float *d_R, float *d_T, float *d_q, float *d_scale, int B, int N, int J, long long row_offset,
+                            void *stream) {
+    if (!d_x0 || !d_uv || !d_K || !h_keylist || !d_R || !d_T || B < 1 || N < 1 || J < 1 || k < 1 || k > 17 ||
+        iters < 0 || !(normaliser > 0) || row_offset < 0)
+        return ZEDO_E_BADARG;
+    for (int i = 0; i < k; ++i)
+        if (h_keylist[i] < 0 || h_keylist[i] >= J) return ZEDO_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    int *d_kl = nullptr;
+    HIPCHK(hipMalloc(&d_kl, sizeof(int) * k));
+    hipError_t e = hipMemcpyAsync(d_kl, h_keylist, sizeof(int) * k, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = launch_ipo_fit(d_x0, d_uv, d_K, d_kl, k, axes_mask, ipo_T, min_scale, max_scale, iters, normaliser, d_R, d_T,
+                           d_q, d_scale, B, N, J, row_offset, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // d_kl is freed below; h_keylist may be pageable
+    (void)hipFree(d_kl);
+    return (int)e;
+}
+
+extern "C" int zedo_rotate_init(const float *d_x0, const float *d_R, float *d_x, int B, int N, int J, long long row_offset,
+                                void *stream) {
+    if (!d_x0 || !d_R || !d_x || B < 1 || N < 1 || J < 1 || row_offset < 0) return ZEDO_E_BADARG;
+    HIPCHK(launch_rotate_init(d_x0, d_R, d_x, B, N, J, row_offset, (hipStream_t)stream));
+    return ZEDO_OK;
+}
+
+extern "C" int zedo_min_mpjpe(const float *d_pred, const double *d_gt, int B, int N, int J, long long row_offset,
+                              int procrustes, double *d_err, double *d_best, int *d_best_h, void *stream) {
+    if (!d_pred || !d_gt || !d_err || !d_best || !d_best_h || B < 1 || N < 1 || J < 1 || row_offset < 0)
+        return ZEDO_E_BADARG;
+    HIPCHK(launch_min_mpjpe(d_pred, d_gt, B, N, J, row_offset, procrustes, d_err, d_best, d_best_h, (hipStream_t)stream));
+    return ZEDO_OK;
+}

@@ -1,0 +1,419 @@
+// Geometry side of the ZeDO loop for gfx950: reprojection correction (gradient_field_gen),
+// the in-register IPO fit, and the small packing / table kernels around them.
+// These kernels are HBM/latency bound (about 1.5 kFLOP and a few hundred bytes per row):
+// global traffic is coalesced through LDS tiles, each lane then owns one pose row.
+#include "zedo_internal.h"
+
+namespace zedo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// geom[n][j] = 8 floats: { r_x, r_y, W, 0,  rhat_x, rhat_y, rhat_z, 0 }
+constexpr int GEOM_F = 8;
+
+// ------------------------------------------------------------------------------------------
+// pose rows [B][D] <-> padded rows [Bp][XLD] (pad columns and pad rows are zero)
+// ------------------------------------------------------------------------------------------
+__global__ void pack_rows_kernel(const float *__restrict__ x, float *__restrict__ xpad, int B, int Bp, int D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Bp * XLD) return;
+    const int r = (int)(i / XLD), c = (int)(i % XLD);
+    xpad[i] = (r < B && c < D) ? x[(size_t)r * D + c] : 0.0f;
+}
+
+__global__ void unpack_rows_kernel(const float *__restrict__ xpad, float *__restrict__ x, int B, int D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * D) return;
+    const int r = (int)(i / D), c = (int)(i % D);
+    x[i] = xpad[(size_t)r * XLD + c];
+}
+
+hipError_t launch_pack_rows(const float *x, float *xpad, int B, int Bp, int D, hipStream_t st) {
+    const size_t n = (size_t)Bp * XLD;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, xpad, B, Bp, D);
+    return hipGetLastError();
+}
+hipError_t launch_unpack_rows(const float *xpad, float *x, int B, int D, hipStream_t st) {
+    const size_t n = (size_t)B * D;
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xpad, x, B, D);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// step-invariant rays (reference simple_zeroshot_opt.py:61-71,99 and conf clamp :64-66)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void inv3x3(const float *K, double *Ki) {
+    const double a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+    const double A = e * i - f * h, Bc = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * Bc + c * C;
+    const double id = 1.0 / det;
+    Ki[0] = A * id;  Ki[1] = -(b * i - c * h) * id;  Ki[2] = (b * f - c * e) * id;
+    Ki[3] = Bc * id; Ki[4] = (a * i - c * g) * id;   Ki[5] = -(a * f - c * d) * id;
+    Ki[6] = C * id;  Ki[7] = -(a * h - b * g) * id;  Ki[8] = (a * e - b * d) * id;
+}
+
+__global__ void reproj_prepare_kernel(const float *__restrict__ uv, const float *__restrict__ K,
+                                      const float *__restrict__ conf, int N, int J, float *__restrict__ geom,
+                                      float *__restrict__ conf_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * J) return;
+    const int n = i / J;
+    double Ki[9];
+    inv3x3(K + (size_t)n * 9, Ki);
+    const double u = uv[(size_t)i * 2], v = uv[(size_t)i * 2 + 1];
+    const double rz = Ki[6] * u + Ki[7] * v + Ki[8];
+    const double rx = (Ki[0] * u + Ki[1] * v + Ki[2]) / rz;
+    const double ry = (Ki[3] * u + Ki[4] * v + Ki[5]) / rz;
+    const double rn = 1.0 / sqrt(rx * rx + ry * ry + 1.0);
+    float W = 1.0f;
+    if (conf) {
+        float c = conf[i];
+        if (c > 1.0f) c = 1.0f;      // NaN stays NaN, exactly like the masked assignment of the reference
+        if (c < 1e-4f) c = 1e-4f;
+        if (conf_out) conf_out[i] = c;
+        const float w = c * c;       // rows of A and b are scaled by conf^2 (:85-88) ...
+        W = w * w;                   // ... so the normal equations weight each residual by conf^4
+    }
+    float *g = geom + (size_t)i * GEOM_F;
+    g[0] = (float)rx; g[1] = (float)ry; g[2] = W; g[3] = 0.0f;
+    g[4] = (float)(rx * rn); g[5] = (float)(ry * rn); g[6] = (float)rn; g[7] = 0.0f;
+}
+
+hipError_t launch_reproj_prepare(const float *uv, const float *K, const float *conf, int N, int J, float *geom,
+                                 float *conf_clamped, hipStream_t st) {
+    const int n = N * J;
+    hipLaunchKernelGGL(reproj_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, st, uv, K, conf, N, J, geom,
+                       conf_clamped);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// gradient_field_gen for one pose row held in registers (simple_zeroshot_opt.py:73-109)
+// ------------------------------------------------------------------------------------------
+// Weighted least squares for T, centred closed form of the 3x3 normal equations of :73-92:
+//   minimise sum_j W_j [(-T_x + r_xj T_z - b_xj)^2 + (-T_y + r_yj T_z - b_yj)^2],  b = x_xy - x_z r_xy
+//   T_z = sum W[(r_x-rbar_x)(b_x-bbar_x) + (r_y-rbar_y)(b_y-bbar_y)] / sum W[(r_x-rbar_x)^2 + (r_y-rbar_y)^2]
+//   T_xy = rbar_xy T_z - bbar_xy ;  T <- -T if T_z < 0 (:93)
+template <int J>
+__device__ __forceinline__ void reproj_row(const float *x, const float *__restrict__ gp, float *T, bool solve,
+                                           float *g) {
+    if (solve) {
+        float sw = 0.f, srx = 0.f, sry = 0.f, sbx = 0.f, sby = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(gp + j * GEOM_F);
+            const float bx = x[3 * j] - x[3 * j + 2] * a[0], by = x[3 * j + 1] - x[3 * j + 2] * a[1];
+            sw += a[2]; srx += a[2] * a[0]; sry += a[2] * a[1]; sbx += a[2] * bx; sby += a[2] * by;
+        }
+        const float iw = 1.0f / sw;
+        const float mrx = srx * iw, mry = sry * iw, mbx = sbx * iw, mby = sby * iw;
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(gp + j * GEOM_F);
+            const float bx = x[3 * j] - x[3 * j + 2] * a[0], by = x[3 * j + 1] - x[3 * j + 2] * a[1];
+            const float dx = a[0] - mrx, dy = a[1] - mry;
+            num += a[2] * (dx * (bx - mbx) + dy * (by - mby));
+            den += a[2] * (dx * dx + dy * dy);
+        }
+        float tz = num / den;
+        float tx = mrx * tz - mbx, ty = mry * tz - mby;
+        if (tz < 0.f) { tx = -tx; ty = -ty; tz = -tz; }
+        T[0] = tx; T[1] = ty; T[2] = tz;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const f32x4 rh = *reinterpret_cast<const f32x4 *>(gp + j * GEOM_F + 4);
+        const float px = x[3 * j] + T[0], py = x[3 * j + 1] + T[1], pz = x[3 * j + 2] + T[2];
+        const float d = px * rh[0] + py * rh[1] + pz * rh[2];
+        g[3 * j] = d * rh[0] - px;
+        g[3 * j + 1] = d * rh[1] - py;
+        g[3 * j + 2] = d * rh[2] - pz;
+    }
+}
+
+// Standalone surface op: x [B][J*3] -> g [B][J*3] (+T).  128 rows per workgroup, tile staged through
+// LDS with unit-stride global accesses; odd row stride (51) keeps the per-lane row reads conflict free.
+template <int J>
+__global__ __launch_bounds__(128) void reproj_grad_kernel(const float *__restrict__ x, const float *__restrict__ geom,
+                                                          float *__restrict__ T, int solve, float *__restrict__ gout,
+                                                          int B, int N, long long row_offset) {
+    constexpr int D = J * 3, R = 128;
+    __shared__ float sx[R * D];
+    const int row0 = blockIdx.x * R, tid = threadIdx.x;
+    const int rows = min(R, B - row0);
+    const float *src = x + (size_t)row0 * D;
+    for (int i = tid; i < rows * D; i += R) sx[i] = src[i];
+    __syncthreads();
+    float xr[D], gr[D], Tr[3];
+    if (tid < rows) {
+        const int b = row0 + tid;
+#pragma unroll
+        for (int c = 0; c < D; ++c) xr[c] = sx[tid * D + c];
+        Tr[0] = T[(size_t)b * 3]; Tr[1] = T[(size_t)b * 3 + 1]; Tr[2] = T[(size_t)b * 3 + 2];
+        const int n = (int)((row_offset + b) % N);
+        reproj_row<J>(xr, geom + (size_t)n * J * GEOM_F, Tr, solve != 0, gr);
+        if (solve) { T[(size_t)b * 3] = Tr[0]; T[(size_t)b * 3 + 1] = Tr[1]; T[(size_t)b * 3 + 2] = Tr[2]; }
+    }
+    __syncthreads();
+    if (tid < rows) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) sx[tid * D + c] = gr[c];
+    }
+    __syncthreads();
+    float *dst = gout + (size_t)row0 * D;
+    for (int i = tid; i < rows * D; i += R) dst[i] = sx[i];
+}
+
+hipError_t launch_reproj_grad(const float *x, const float *geom, float *T, int solve_T, float *g, int B, int N,
+                              int J, long long row_offset, hipStream_t st) {
+    if (J != 17) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(reproj_grad_kernel<17>, dim3((B + 127) / 128), dim3(128), 0, st, x, geom, T, solve_T, g, B, N,
+                       row_offset);
+    return hipGetLastError();
+}
+
+// Fused-loop variant on the padded state: xpad[row][64] += g, in place.  128 rows per workgroup:
+// the 32 KB tile moves as 16-byte, fully coalesced accesses through LDS (row stride 68 floats so
+// that each lane's ds_read_b128 / ds_write_b128 of its own row is bank-conflict free).
+template <int J>
+__global__ __launch_bounds__(128) void reproj_step_kernel(float *__restrict__ xpad, const float *__restrict__ geom,
+                                                          float *__restrict__ T, int solve, int B, int N,
+                                                          long long row_offset) {
+    constexpr int D = J * 3, R = 128, LD = XLD + 4, NV = (D + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float sx[R * LD];
+    const int row0 = blockIdx.x * R, tid = threadIdx.x;
+    float *base = xpad + (size_t)row0 * XLD;  // Bp is a multiple of 256: the whole tile exists
+#pragma unroll
+    for (int it = 0; it < XLD / 4; ++it) {
+        const int idx = it * R + tid, r = idx >> 4, c4 = idx & 15;
+        *reinterpret_cast<f32x4 *>(sx + r * LD + c4 * 4) = *reinterpret_cast<const f32x4 *>(base + (size_t)idx * 4);
+    }
+    __syncthreads();
+    const int b = row0 + tid;
+    if (b < B) {
+        float xr[NV * 4], gr[D], Tr[3];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(sx + tid * LD + v * 4);
+            xr[4 * v] = t[0]; xr[4 * v + 1] = t[1]; xr[4 * v + 2] = t[2]; xr[4 * v + 3] = t[3];
+        }
+        Tr[0] = T[(size_t)b * 3]; Tr[1] = T[(size_t)b * 3 + 1]; Tr[2] = T[(size_t)b * 3 + 2];
+        const int n = (int)((row_offset + b) % N);
+        reproj_row<J>(xr, geom + (size_t)n * J * GEOM_F, Tr, solve != 0, gr);
+        if (solve) { T[(size_t)b * 3] = Tr[0]; T[(size_t)b * 3 + 1] = Tr[1]; T[(size_t)b * 3 + 2] = Tr[2]; }
+#pragma unroll
+        for (int c = 0; c < D; ++c) xr[c] += gr[c];  // denoise_x += joint_gradient (run/opt_main.py:208)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            f32x4 t = {xr[4 * v], xr[4 * v + 1], xr[4 * v + 2], xr[4 * v + 3]};
+            *reinterpret_cast<f32x4 *>(sx + tid * LD + v * 4) = t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < XLD / 4; ++it) {
+        const int idx = it * R + tid, r = idx >> 4, c4 = idx & 15;
+        *reinterpret_cast<f32x4 *>(base + (size_t)idx * 4) = *reinterpret_cast<const f32x4 *>(sx + r * LD + c4 * 4);
+    }
+}
+
+hipError_t launch_reproj_step_padded(float *xpad, const float *geom, float *T, int solve_T, int B, int N,
+                                     long long row0, hipStream_t st) {
+    hipLaunchKernelGGL(reproj_step_kernel<17>, dim3((B + 127) / 128), dim3(128), 0, st, xpad, geom, T, solve_T, B, N,
+                       row0);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// sinusoidal timestep embedding (model.py:81-95) for labels = 999 t  (utils.py:762)
+// ------------------------------------------------------------------------------------------
+__global__ void posemb_kernel(const float *__restrict__ t, int S, int Sp, float *__restrict__ pe) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Sp * EMB) return;
+    const int s = i / EMB, c = i % EMB;
+    float o = 0.0f;
+    if (s < S) {
+        constexpr int half = EMB / 2;
+        const float emb = (float)(-9.210340371976184 / (half - 1));  // -log(10000)/(half-1), rounded like the fp32 mul
+        const int k = c < half ? c : c - half;
+        const float freq = expf((float)k * emb);
+        const float arg = (t[s] * 999.0f) * freq;
+        o = c < half ? sinf(arg) : cosf(arg);
+    }
+    pe[i] = o;
+}
+
+hipError_t launch_posemb(const float *t, int S, int Sp, float *pe, hipStream_t st) {
+    const int n = Sp * EMB;
+    hipLaunchKernelGGL(posemb_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t, S, Sp, pe);
+    return hipGetLastError();
+}
+
+__global__ void add_rows_kernel(float *__restrict__ o, const float *__restrict__ a, const float *__restrict__ b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+hipError_t launch_add_bias_rows(float *b_sum, const float *b1, const float *b2, int n, hipStream_t st) {
+    hipLaunchKernelGGL(add_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b_sum, b1, b2, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// IPO: RotOpt + L1 reprojection loss + Adam, all iterations in registers
+// (run/opt_main.py:177-195, simple_zeroshot_opt.py:8-31, utils.py:59-88)
+// ------------------------------------------------------------------------------------------
+struct AdamP {
+    float p, m, v;
+    __device__ __forceinline__ void step(float g, float step_size, float bc2_sqrt) {
+        // torch.optim.Adam single-tensor update: lerp, mul+addcmul, sqrt/bc2_sqrt + eps, addcdiv
+        m = m + (g - m) * 0.1f;                       // 1 - beta1, beta1 = 0.9
+        v = v * 0.999f + 0.001f * g * g;              // beta2 = 0.999
+        const float denom = sqrtf(v) / bc2_sqrt + 1e-8f;
+        p = p + (-step_size * m) / denom;
+    }
+};
+
+__device__ __forceinline__ float sgnf(float e) { return (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f); }
+
+constexpr int IPO_TB = 128;
+constexpr int IPO_KMAX = 17;
+
+__global__ __launch_bounds__(IPO_TB) void ipo_kernel(const float *__restrict__ x0, const float *__restrict__ uv,
+                                                     const float *__restrict__ Kmat, const int *__restrict__ keylist,
+                                                     int k, int axes_mask, float ipo_T, float min_s, float max_s,
+                                                     int iters, float inv_norm, float *__restrict__ Rout,
+                                                     float *__restrict__ Tout, float *__restrict__ qout,
+                                                     float *__restrict__ sout, int B, int N, int J,
+                                                     long long row_offset) {
+    __shared__ float s_cu[IPO_KMAX][IPO_TB], s_cv[IPO_KMAX][IPO_TB];
+    __shared__ int s_kl[IPO_KMAX];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x * IPO_TB + tid;
+    if (tid < k) s_kl[tid] = keylist[tid];
+    __syncthreads();
+    if (b >= B) return;
+    const long long gb = row_offset + b;
+    const int n = (int)(gb % N), h = (int)(gb / N);
+    const float *xh = x0 + (size_t)h * J * 3;
+    for (int jj = 0; jj < k; ++jj) {
+        s_cu[jj][tid] = uv[((size_t)n * J + s_kl[jj]) * 2];
+        s_cv[jj][tid] = uv[((size_t)n * J + s_kl[jj]) * 2 + 1];
+    }
+    float K[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) K[i] = Kmat[(size_t)n * 9 + i];
+    // T0 = ipo_T * normalise(Kinv [u0 v0 1])  (opt_main.py:177-179); joint 0 is the pelvis
+    float T0[3];
+    {
+        double Ki[9];
+        inv3x3(K, Ki);
+        const double u = uv[(size_t)n * J * 2], v = uv[(size_t)n * J * 2 + 1];
+        const double tx = Ki[0] * u + Ki[1] * v + Ki[2], ty = Ki[3] * u + Ki[4] * v + Ki[5],
+                     tz = Ki[6] * u + Ki[7] * v + Ki[8];
+        const double in = (double)ipo_T / sqrt(tx * tx + ty * ty + tz * tz);
+        T0[0] = (float)(tx * in); T0[1] = (float)(ty * in); T0[2] = (float)(tz * in);
+    }
+    AdamP qr{1.f, 0.f, 0.f}, qi{0.f, 0.f, 0.f}, qj{0.f, 0.f, 0.f}, qk{0.f, 0.f, 0.f}, sc{1.f, 0.f, 0.f};
+    const bool ax = axes_mask & 1, ay = axes_mask & 2, az = axes_mask & 4;
+    double b1p = 1.0, b2p = 1.0;
+    for (int it = 0; it < iters; ++it) {
+        const float r = qr.p, i = qi.p, j = qj.p, kk = qk.p;
+        const float n2 = r * r + i * i + j * j + kk * kk;
+        const float ts = 2.0f / n2;
+        // R = I + ts * Q(q)  (quaternion_to_matrix, utils.py:59-88)
+        const float R00 = 1.f - ts * (j * j + kk * kk), R01 = ts * (i * j - kk * r), R02 = ts * (i * kk + j * r);
+        const float R10 = ts * (i * j + kk * r), R11 = 1.f - ts * (i * i + kk * kk), R12 = ts * (j * kk - i * r);
+        const float R20 = ts * (i * kk - j * r), R21 = ts * (j * kk + i * r), R22 = 1.f - ts * (i * i + j * j);
+        const float scc = fminf(fmaxf(sc.p, min_s), max_s);
+        const float Tx = T0[0] * scc, Ty = T0[1] * scc, Tz = T0[2] * scc;
+        float G00 = 0, G01 = 0, G02 = 0, G10 = 0, G11 = 0, G12 = 0, G20 = 0, G21 = 0, G22 = 0, gsc = 0;
+        for (int jj = 0; jj < k; ++jj) {
+            const int jn = s_kl[jj];
+            const float x = xh[jn * 3], y = xh[jn * 3 + 1], z = xh[jn * 3 + 2];
+            const float px = R00 * x + R01 * y + R02 * z + Tx;
+            const float py = R10 * x + R11 * y + R12 * z + Ty;
+            const float pz = R20 * x + R21 * y + R22 * z + Tz;
+            const float w0 = K[0] * px + K[1] * py + K[2] * pz;
+            const float w1 = K[3] * px + K[4] * py + K[5] * pz;
+            const float w2 = K[6] * px + K[7] * py + K[8] * pz;
+            const float gu = sgnf(w0 / w2 - s_cu[jj][tid]) * inv_norm;   // d mean|e| / du
+            const float gv = sgnf(w1 / w2 - s_cv[jj][tid]) * inv_norm;
+            const float gw0 = gu / w2, gw1 = gv / w2;
+            const float gw2 = -gu * ((w0 / w2) / w2) - gv * ((w1 / w2) / w2);  // torch div backward form
+            const float gpx = K[0] * gw0 + K[3] * gw1 + K[6] * gw2;       // K^T g_w
+            const float gpy = K[1] * gw0 + K[4] * gw1 + K[7] * gw2;
+            const float gpz = K[2] * gw0 + K[5] * gw1 + K[8] * gw2;
+            gsc += gpx * T0[0] + gpy * T0[1] + gpz * T0[2];
+            G00 += gpx * x; G01 += gpx * y; G02 += gpx * z;
+            G10 += gpy * x; G11 += gpy * y; G12 += gpy * z;
+            G20 += gpz * x; G21 += gpz * y; G22 += gpz * z;
+        }
+        // dL/d two_s = <G, Q>
+        const float gts = G00 * -(j * j + kk * kk) + G01 * (i * j - kk * r) + G02 * (i * kk + j * r) +
+                          G10 * (i * j + kk * r) + G11 * -(i * i + kk * kk) + G12 * (j * kk - i * r) +
+                          G20 * (i * kk - j * r) + G21 * (j * kk + i * r) + G22 * -(i * i + j * j);
+        const float dts = -gts * ts * ts;  // d two_s / d q_c = -two_s^2 q_c
+        const float gr = ts * (-G01 * kk + G02 * j + G10 * kk - G12 * i - G20 * j + G21 * i) + dts * r;
+        const float gi = ts * (G01 * j + G02 * kk + G10 * j - 2.f * G11 * i - G12 * r + G20 * kk + G21 * r - 2.f * G22 * i) + dts * i;
+        const float gj = ts * (-2.f * G00 * j + G01 * i + G02 * r + G10 * i + G12 * kk - G20 * r + G21 * kk - 2.f * G22 * j) + dts * j;
+        const float gk = ts * (-2.f * G00 * kk - G01 * r + G02 * i + G10 * r - 2.f * G11 * kk + G12 * j + G20 * i + G21 * j) + dts * kk;
+        const float gs = (sc.p >= min_s && sc.p <= max_s) ? gsc : 0.f;   // clamp backward
+        b1p *= 0.9; b2p *= 0.999;
+        const float step_size = (float)(0.1 / (1.0 - b1p));
+        const float bc2s = (float)sqrt(1.0 - b2p);
+        qr.step(gr, step_size, bc2s);
+        if (ax) qi.step(gi, step_size, bc2s);
+        if (ay) qj.step(gj, step_size, bc2s);
+        if (az) qk.step(gk, step_size, bc2s);
+        sc.step(gs, step_size, bc2s);
+    }
+    {
+        const float r = qr.p, i = qi.p, j = qj.p, kk = qk.p;
+        const float ts = 2.0f / (r * r + i * i + j * j + kk * kk);
+        float *Ro = Rout + (size_t)b * 9;
+        Ro[0] = 1.f - ts * (j * j + kk * kk); Ro[1] = ts * (i * j - kk * r); Ro[2] = ts * (i * kk + j * r);
+        Ro[3] = ts * (i * j + kk * r); Ro[4] = 1.f - ts * (i * i + kk * kk); Ro[5] = ts * (j * kk - i * r);
+        Ro[6] = ts * (i * kk - j * r); Ro[7] = ts * (j * kk + i * r); Ro[8] = 1.f - ts * (i * i + j * j);
+        const float scc = fminf(fmaxf(sc.p, min_s), max_s);
+        Tout[(size_t)b * 3] = T0[0] * scc; Tout[(size_t)b * 3 + 1] = T0[1] * scc; Tout[(size_t)b * 3 + 2] = T0[2] * scc;
+        if (qout) { qout[(size_t)b * 4] = r; qout[(size_t)b * 4 + 1] = i; qout[(size_t)b * 4 + 2] = j; qout[(size_t)b * 4 + 3] = kk; }
+        if (sout) sout[b] = sc.p;
+    }
+}
+
+hipError_t launch_ipo_fit(const float *x0, const float *uv, const float *K, const int *d_keylist, int k,
+                          int axes_mask, float ipo_T, float min_scale, float max_scale, int iters,
+                          double normaliser, float *R, float *T, float *q, float *scale, int B, int N, int J,
+                          long long row_offset, hipStream_t st) {
+    if (k < 1 || k > IPO_KMAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ipo_kernel, dim3((B + IPO_TB - 1) / IPO_TB), dim3(IPO_TB), 0, st, x0, uv, K, d_keylist, k,
+                       axes_mask, ipo_T, min_scale, max_scale, iters, (float)(1.0 / normaliser), R, T, q, scale, B, N,
+                       J, row_offset);
+    return hipGetLastError();
+}
+
+// x[b] = R[b] . x0[h]  (run/opt_main.py:201)
+__global__ void rotate_init_kernel(const float *__restrict__ x0, const float *__restrict__ R, float *__restrict__ x,
+                                   int B, int N, int J, long long row_offset) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * J) return;
+    const int b = (int)(i / J), j = (int)(i % J);
+    const int h = (int)((row_offset + b) / N);
+    const float *r = R + (size_t)b * 9;
+    const float *p = x0 + ((size_t)h * J + j) * 3;
+    const float a = p[0], c = p[1], d = p[2];
+    x[i * 3] = r[0] * a + r[1] * c + r[2] * d;
+    x[i * 3 + 1] = r[3] * a + r[4] * c + r[5] * d;
+    x[i * 3 + 2] = r[6] * a + r[7] * c + r[8] * d;
+}
+
+hipError_t launch_rotate_init(const float *x0, const float *R, float *x, int B, int N, int J, long long row_offset,
+                              hipStream_t st) {
+    const size_t n = (size_t)B * J;
+    hipLaunchKernelGGL(rotate_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x0, R, x, B, N, J,
+                       row_offset);
+    return hipGetLastError();
+}
+
+}  // namespace zedo

@@ -1,0 +1,148 @@
+// Hypothesis selection for gfx950: per-(hypothesis,pose) MPJPE / Procrustes-aligned MPJPE in fp64 and the
+// per-pose minimum over hypotheses (reference lib/dataset/h36m.py:394-417, lib/dataset/pw3d.py:302-331,
+// lib/utils/transforms.py:42-127).  One lane per row for the errors; one wavefront per pose for the
+// arg-min (lanes stride over hypotheses, butterfly reduction with __shfl_xor).
+#include "zedo_internal.h"
+
+namespace zedo {
+
+// One-sided Jacobi on the 3x3 matrix M (columns rotated until orthogonal): M V = U diag(s).
+// Returns R = V U^T (the rotation/reflection of procrustes(..., reflection='best'), transforms.py:93-96)
+// and the sum of singular values.
+__device__ void polar_from_svd(double M[3][3], double R[3][3], double &strace) {
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double al = 0, be = 0, ga = 0;
+                for (int i = 0; i < 3; ++i) { al += M[i][p] * M[i][p]; be += M[i][q] * M[i][q]; ga += M[i][p] * M[i][q]; }
+                if (fabs(ga) <= 1e-300 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+                off = fmax(off, fabs(ga) / sqrt(al * be));
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int i = 0; i < 3; ++i) {
+                    const double mp = M[i][p], mq = M[i][q];
+                    M[i][p] = c * mp - s * mq; M[i][q] = s * mp + c * mq;
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = c * vp - s * vq; V[i][q] = s * vp + c * vq;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    double s[3], U[3][3];
+    double smax = 0;
+    for (int c = 0; c < 3; ++c) {
+        s[c] = sqrt(M[0][c] * M[0][c] + M[1][c] * M[1][c] + M[2][c] * M[2][c]);
+        smax = fmax(smax, s[c]);
+    }
+    int nbad = 0, bad = -1;
+    for (int c = 0; c < 3; ++c) {
+        if (s[c] > 1e-14 * smax && s[c] > 0) {
+            for (int i = 0; i < 3; ++i) U[i][c] = M[i][c] / s[c];
+        } else { ++nbad; bad = c; }
+    }
+    if (nbad == 1) {
+        // rank-2 input (planar pose): complete U with the cross product of the other two columns and pick
+        // the sign that makes R a proper rotation.  numpy's LAPACK picks an arbitrary sign here.
+        const int a = (bad + 1) % 3, b = (bad + 2) % 3;
+        U[0][bad] = U[1][a] * U[2][b] - U[2][a] * U[1][b];
+        U[1][bad] = U[2][a] * U[0][b] - U[0][a] * U[2][b];
+        U[2][bad] = U[0][a] * U[1][b] - U[1][a] * U[0][b];
+        const double detV = V[0][0] * (V[1][1] * V[2][2] - V[1][2] * V[2][1]) - V[0][1] * (V[1][0] * V[2][2] - V[1][2] * V[2][0]) +
+                            V[0][2] * (V[1][0] * V[2][1] - V[1][1] * V[2][0]);
+        if (detV < 0) for (int i = 0; i < 3; ++i) U[i][bad] = -U[i][bad];
+        s[bad] = 0;
+    } else if (nbad > 1) {
+        for (int c = 0; c < 3; ++c) for (int i = 0; i < 3; ++i) U[i][c] = (i == c);
+        for (int c = 0; c < 3; ++c) for (int i = 0; i < 3; ++i) V[i][c] = (i == c);
+    }
+    strace = s[0] + s[1] + s[2];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[i][j] = V[i][0] * U[j][0] + V[i][1] * U[j][1] + V[i][2] * U[j][2];
+}
+
+__global__ void row_error_kernel(const float *__restrict__ pred, const double *__restrict__ gt, int B, int N, int J,
+                                 long long row_offset, int procrustes, double *__restrict__ err) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n = (int)((row_offset + b) % N);
+    const float *p = pred + (size_t)b * J * 3;
+    const double *g = gt + (size_t)n * J * 3;
+    double e = 0.0;
+    if (!procrustes) {
+        for (int j = 0; j < J; ++j) {
+            const double dx = (double)p[3 * j] - g[3 * j], dy = (double)p[3 * j + 1] - g[3 * j + 1],
+                         dz = (double)p[3 * j + 2] - g[3 * j + 2];
+            e += sqrt(dx * dx + dy * dy + dz * dz);
+        }
+        err[b] = e / J;
+        return;
+    }
+    // procrustes(A = gt, B = pred, scaling=True, reflection='best').Z  (transforms.py:42-127)
+    double ab[3] = {0, 0, 0}, bb[3] = {0, 0, 0};
+    for (int j = 0; j < J; ++j)
+        for (int c = 0; c < 3; ++c) { ab[c] += g[3 * j + c]; bb[c] += (double)p[3 * j + c]; }
+    for (int c = 0; c < 3; ++c) { ab[c] /= J; bb[c] /= J; }
+    double ssA = 0, ssB = 0, M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int j = 0; j < J; ++j) {
+        double a0[3], b0[3];
+        for (int c = 0; c < 3; ++c) { a0[c] = g[3 * j + c] - ab[c]; b0[c] = (double)p[3 * j + c] - bb[c]; }
+        for (int c = 0; c < 3; ++c) { ssA += a0[c] * a0[c]; ssB += b0[c] * b0[c]; }
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) M[r][c] += a0[r] * b0[c];   // A0^T B0 (un-normalised)
+    }
+    const double An = sqrt(ssA), Bn = sqrt(ssB);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) M[r][c] /= (An * Bn);
+    double R[3][3], st;
+    polar_from_svd(M, R, st);
+    const double scale = An * st / Bn;   // Z = A_norm * S_trace * (B0/B_norm) R + A_bar
+    for (int j = 0; j < J; ++j) {
+        double b0[3], z[3];
+        for (int c = 0; c < 3; ++c) b0[c] = (double)p[3 * j + c] - bb[c];
+        for (int c = 0; c < 3; ++c) z[c] = scale * (b0[0] * R[0][c] + b0[1] * R[1][c] + b0[2] * R[2][c]) + ab[c];
+        const double dx = z[0] - g[3 * j], dy = z[1] - g[3 * j + 1], dz = z[2] - g[3 * j + 2];
+        e += sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    err[b] = e / J;
+}
+
+// one wavefront per pose: min / first arg-min (np.argmin tie rule) over the hypotheses held locally
+__global__ void pose_min_kernel(const double *__restrict__ err, int B, int N, long long row_offset,
+                                double *__restrict__ best, int *__restrict__ best_h) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    // global rows of pose n: n, n+N, n+2N, ... ; local index = global - row_offset
+    long long h0 = (row_offset - n + N - 1) / N;     // first hypothesis with h*N + n >= row_offset
+    if (row_offset <= n) h0 = 0;
+    double e = __builtin_huge_val();
+    int hi = -1;
+    for (long long h = h0 + lane;; h += 64) {
+        const long long loc = h * N + n - row_offset;
+        if (loc >= B) break;
+        const double v = err[loc];
+        if (hi < 0 || v < e) { e = v; hi = (int)h; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double oe = __shfl_xor(e, off);
+        const int oh = __shfl_xor(hi, off);
+        const bool take = (oh >= 0) && (hi < 0 || oe < e || (oe == e && oh < hi));
+        if (take) { e = oe; hi = oh; }
+    }
+    if (lane == 0) { best[n] = (hi >= 0) ? e : __builtin_huge_val(); best_h[n] = hi; }
+}
+
+hipError_t launch_min_mpjpe(const float *pred, const double *gt, int B, int N, int J, long long row_offset,
+                            int procrustes, double *err, double *best, int *best_h, hipStream_t st) {
+    hipLaunchKernelGGL(row_error_kernel, dim3((B + 127) / 128), dim3(128), 0, st, pred, gt, B, N, J, row_offset,
+                       procrustes, err);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pose_min_kernel, dim3((N + 3) / 4), dim3(256), 0, st, err, B, N, row_offset, best, best_h);
+    return hipGetLastError();
+}
+
+}  // namespace zedo

@@ -1,0 +1,277 @@
+"""ctypes binding of libzedo_hip.so (C ABI: include/zedo_hip.h) for torch tensors on an MI355X.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every arithmetic step of the
+ZeDO hot path runs in the hand-written gfx950 kernels behind the C ABI.  There is NO fallback:
+importing this module without the built library, or calling it without a GPU, raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzedo_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C zedo-release_amd/csrc` (or "
+        "__graft_entry__.build()).  The ZeDO hot path has no CPU or PyTorch fallback.")
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+_vp, _i, _f, _d, _ll, _sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double,
+                             ctypes.c_longlong, ctypes.c_size_t)
+
+# name -> (restype, argtypes): every symbol declared in include/zedo_hip.h
+SIGNATURES = {
+    "zedo_abi_version": (_i, []),
+    "zedo_error_string": (ctypes.c_char_p, [_i]),
+    "zedo_weights_create": (_i, [_vp, _sz, _i, _i, _i, _i, _i, _vp, ctypes.POINTER(_vp)]),
+    "zedo_weights_destroy": (None, [_vp]),
+    "zedo_schedule_create": (_i, [_vp, _vp, _i, _f, _f, _i, _vp, ctypes.POINTER(_vp)]),
+    "zedo_schedule_destroy": (None, [_vp]),
+    "zedo_schedule_read": (_i, [_vp, _vp, _vp, _vp]),
+    "zedo_workspace_bytes": (_sz, [_i]),
+    "zedo_reproj_prepare": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "zedo_reproj_grad": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _ll, _vp]),
+    "zedo_score_eps": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "zedo_sde_step": (_i, [_vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "zedo_oil_run": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _vp, _sz, _vp]),
+    "zedo_ipo_fit": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _vp]),
+    "zedo_rotate_init": (_i, [_vp, _vp, _vp, _i, _i, _i, _ll, _vp]),
+    "zedo_min_mpjpe": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp]),
+    "zedo_profile_start": (_i, [_i, _i]),
+    "zedo_profile_stop": (_i, [_vp, _vp, _vp]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(_lib, _name)  # AttributeError here = library/header mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+N_JOINTS, JOINT_DIM, HIDDEN_DIM, EMBED_DIM = 17, 3, 1024, 512
+GEOM_F = 8
+
+
+class ZedoError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise ZedoError(f"libzedo_hip: {_lib.zedo_error_string(rc).decode()} (code {rc})")
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        raise ZedoError("libzedo_hip needs an MI355X (gfx950): no GPU is visible and there is no CPU path")
+
+
+def _p(t, dtype=torch.float32):
+    """device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype == dtype):
+        raise ZedoError(f"expected a contiguous {dtype} CUDA tensor, got {type(t)} "
+                        f"{getattr(t, 'dtype', None)} {getattr(t, 'device', None)}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def abi_version():
+    return _lib.zedo_abi_version()
+
+
+# state-dict order of ScoreModelFC_Adv (reference lib/algorithms/advanced/model.py:113-152)
+def param_names(n_blocks=2):
+    names = ["pre_dense.weight", "pre_dense.bias", "pre_dense_t.weight", "pre_dense_t.bias",
+             "pre_gnorm.weight", "pre_gnorm.bias", "shared_time_embed.0.weight", "shared_time_embed.0.bias"]
+    for b in range(1, n_blocks + 1):
+        for k in (1, 2):
+            names += [f"b{b}_dense{k}.weight", f"b{b}_dense{k}.bias", f"b{b}_dense{k}_t.weight",
+                      f"b{b}_dense{k}_t.bias", f"b{b}_gnorm{k}.weight", f"b{b}_gnorm{k}.bias"]
+    return names + ["post_dense.weight", "post_dense.bias"]
+
+
+class Weights:
+    """Device copy of a ScoreModelFC_Adv state dict, repacked for the kernels (zedo_weights_create)."""
+
+    def __init__(self, state_dict, n_joints=N_JOINTS, joint_dim=JOINT_DIM, hidden=HIDDEN_DIM, embed=EMBED_DIM,
+                 n_blocks=2):
+        _need_gpu()
+        flat = []
+        for name in param_names(n_blocks):
+            v = state_dict[name]
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            flat.append(np.ascontiguousarray(v, dtype=np.float32).reshape(-1))
+        flat = np.concatenate(flat)
+        self._h = ctypes.c_void_p()
+        _check(_lib.zedo_weights_create(flat.ctypes.data_as(_vp), flat.size, n_joints, joint_dim, hidden, embed,
+                                        n_blocks, _stream(), ctypes.byref(self._h)))
+        self.n_joints, self.joint_dim, self.hidden, self.embed, self.n_blocks = n_joints, joint_dim, hidden, embed, n_blocks
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.zedo_weights_destroy(h)
+            self._h = None
+
+
+class Schedule:
+    """Per-step tables (time-bias rows, a_i, c_i) for one timestamp vector (zedo_schedule_create)."""
+
+    def __init__(self, weights, ts, beta_min=0.1, beta_max=20.0, n_sde=1000):
+        _need_gpu()
+        ts = np.ascontiguousarray(np.asarray(ts, dtype=np.float32).reshape(-1))
+        self.S = int(ts.size)
+        self.ts = ts
+        self.weights = weights  # keep alive
+        self._h = ctypes.c_void_p()
+        _check(_lib.zedo_schedule_create(weights._h, ts.ctypes.data_as(_vp), self.S, beta_min, beta_max, n_sde,
+                                         _stream(), ctypes.byref(self._h)))
+
+    def read(self):
+        nl = 1 + 2 * self.weights.n_blocks
+        tb = np.empty((self.S, nl, self.weights.hidden), np.float32)
+        a = np.empty(self.S, np.float32)
+        c = np.empty(self.S, np.float32)
+        _check(_lib.zedo_schedule_read(self._h, tb.ctypes.data_as(_vp), a.ctypes.data_as(_vp), c.ctypes.data_as(_vp)))
+        return tb, a, c
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.zedo_schedule_destroy(h)
+            self._h = None
+
+
+def workspace_bytes(B):
+    return int(_lib.zedo_workspace_bytes(int(B)))
+
+
+_ws_cache = {}
+
+
+def workspace(B, device=None):
+    """A cached uint8 CUDA tensor large enough for B rows."""
+    _need_gpu()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    need = workspace_bytes(B)
+    cur = _ws_cache.get(device)
+    if cur is None or cur.numel() < need:
+        _ws_cache[device] = None
+        cur = torch.empty(need, dtype=torch.uint8, device=device)
+        _ws_cache[device] = cur
+    return cur
+
+
+def reproj_prepare(uv, K, conf=None, conf_clamped_out=None):
+    """uv [N,J,2], K [N,3,3], conf [N,J] or None -> geom [N,J,8]."""
+    _need_gpu()
+    N, J = uv.shape[0], uv.shape[1]
+    geom = torch.empty((N, J, GEOM_F), dtype=torch.float32, device=uv.device)
+    _check(_lib.zedo_reproj_prepare(_p(uv), _p(K), _p(conf), N, J, _p(geom), _p(conf_clamped_out), _stream()))
+    return geom
+
+
+def reproj_grad(x, geom, T, solve_T, row_offset=0):
+    """gradient_field_gen body: returns g [B,J,3]; T [B,3] is overwritten when solve_T."""
+    _need_gpu()
+    B, J = x.shape[0], x.shape[1]
+    g = torch.empty_like(x)
+    _check(_lib.zedo_reproj_grad(_p(x), _p(geom), _p(T), int(bool(solve_T)), _p(g), B, geom.shape[0], J,
+                                 int(row_offset), _stream()))
+    return g
+
+
+def score_eps(weights, sched, step, x):
+    _need_gpu()
+    B = x.shape[0]
+    ws = workspace(B, x.device)
+    eps = torch.empty_like(x)
+    _check(_lib.zedo_score_eps(weights._h, sched._h, int(step), _p(x), _p(eps), B, _p(ws, torch.uint8), ws.numel(),
+                               _stream()))
+    return eps
+
+
+def sde_step(weights, sched, step, x):
+    """x <- a x + c eps(x), in place."""
+    _need_gpu()
+    B = x.shape[0]
+    ws = workspace(B, x.device)
+    _check(_lib.zedo_sde_step(weights._h, sched._h, int(step), _p(x), B, _p(ws, torch.uint8), ws.numel(), _stream()))
+    return x
+
+
+def oil_run(weights, sched, x, geom, T, step_begin, step_end, switch_step, row_offset=0):
+    """Fused OIL loop over steps [step_begin, step_end); x [B,J,3] and T [B,3] updated in place."""
+    _need_gpu()
+    B = x.shape[0]
+    ws = workspace(B, x.device)
+    _check(_lib.zedo_oil_run(weights._h, sched._h, _p(x), _p(geom), _p(T), int(step_begin), int(step_end),
+                             int(switch_step), B, geom.shape[0], int(row_offset), _p(ws, torch.uint8), ws.numel(),
+                             _stream()))
+    return x, T
+
+
+def axes_mask(axes):
+    return sum({"x": 1, "y": 2, "z": 4}[a] for a in set(axes))
+
+
+def ipo_fit(x0, uv, K, keylist, axes, ipo_T, min_scale, max_scale, iters, normaliser, B, row_offset=0,
+            return_params=False):
+    """x0 [H,J,3] centred cluster poses, uv [N,J,2], K [N,3,3] -> R [B,3,3], T [B,3] (, q [B,4], scale [B])."""
+    _need_gpu()
+    N, J = uv.shape[0], uv.shape[1]
+    dev = uv.device
+    R = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
+    T = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    q = torch.empty((B, 4), dtype=torch.float32, device=dev) if return_params else None
+    sc = torch.empty((B,), dtype=torch.float32, device=dev) if return_params else None
+    kl = (ctypes.c_int * len(keylist))(*[int(k) for k in keylist])
+    _check(_lib.zedo_ipo_fit(_p(x0), _p(uv), _p(K), ctypes.cast(kl, _vp), len(keylist), axes_mask(axes), float(ipo_T),
+                             float(min_scale), float(max_scale), int(iters), float(normaliser), _p(R), _p(T), _p(q),
+                             _p(sc), B, N, J, int(row_offset), _stream()))
+    return (R, T, q, sc) if return_params else (R, T)
+
+
+def rotate_init(x0, R, N, row_offset=0):
+    _need_gpu()
+    B, J = R.shape[0], x0.shape[1]
+    x = torch.empty((B, J, 3), dtype=torch.float32, device=R.device)
+    _check(_lib.zedo_rotate_init(_p(x0), _p(R), _p(x), B, N, J, int(row_offset), _stream()))
+    return x
+
+
+def min_mpjpe(pred, gt_centred, N, procrustes=False, row_offset=0):
+    """pred [B,J,3] fp32 rows (h,n); gt_centred [N,J,3] float64 -> (err [B], best [N], best_h [N])."""
+    _need_gpu()
+    B, J = pred.shape[0], pred.shape[1]
+    err = torch.empty((B,), dtype=torch.float64, device=pred.device)
+    best = torch.empty((N,), dtype=torch.float64, device=pred.device)
+    best_h = torch.empty((N,), dtype=torch.int32, device=pred.device)
+    _check(_lib.zedo_min_mpjpe(_p(pred), _p(gt_centred, torch.float64), B, N, J, int(row_offset), int(bool(procrustes)),
+                               _p(err, torch.float64), _p(best, torch.float64), _p(best_h, torch.int32), _stream()))
+    return err, best, best_h
+
+
+PROF_CLASSES = ("hidden_dense", "pre_dense", "post_dense_sde", "reproj")
+
+
+def profile_start(sample_every=16, max_samples=8192):
+    _check(_lib.zedo_profile_start(int(sample_every), int(max_samples)))
+
+
+def profile_stop():
+    """-> {class: dict(total_ms, samples, launches, avg_ms)} for the sampled kernel launches."""
+    n = len(PROF_CLASSES)
+    tot = (ctypes.c_double * n)()
+    cnt = (ctypes.c_longlong * n)()
+    seen = (ctypes.c_longlong * n)()
+    _check(_lib.zedo_profile_stop(ctypes.cast(tot, _vp), ctypes.cast(cnt, _vp), ctypes.cast(seen, _vp)))
+    return {k: dict(total_ms=tot[i], samples=int(cnt[i]), launches=int(seen[i]),
+                    avg_ms=(tot[i] / cnt[i] if cnt[i] else None)) for i, k in enumerate(PROF_CLASSES)}
