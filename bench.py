@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py - poses/sec of the ZeDO optimisation-in-the-loop sampling path on MI355X.
+
+One "step" = one full pass of the hot path over one synthetic batch shaped like BASELINE configs[2]
+(3DPW: N=1015 poses x H=50 hypotheses, IPO 500 iterations, S=1000 OIL steps, P1+P2 selection), inputs
+resident in HBM when the timed region starts.  `value` = poses fully processed per second over all
+ranks (N * n_gpus * steps / time); for --gpus > 1 (weak scaling: 1015 poses per GPU) the H*N_total rows are
+sharded contiguously over the ranks and the per-pose minimum is combined with one RCCL MIN all-reduce.
+
+The JSON line also carries
+  roofline     : the dominant kernel (the four 1024x1024 fp32-MFMA dense layers): algorithmic FLOP per launch
+                 / its average launch duration, measured live with sampled HIP events on the launch stream;
+  cpu_baseline : the numpy oracle (a port of the reference) timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "zedo-release_amd"),):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+N_POSES, N_HYPO, S_OIL = 1015, 50, 1000
+FLOP_PER_ROW_STEP = 2 * (51 * 1024 + 4 * 1024 * 1024 + 1024 * 51)   # 8 597 504
+PEAK_FP32_MFMA_TFLOPS = 157.3                                        # MI355X_MICROARCH.md
+
+
+def cpu_baseline(weights, cfg_kw, seed):
+    """Oracle (numpy port of the reference path) on the host: IPO at the reference batch size + a bounded
+    number of OIL steps, extrapolated per pose-hypothesis.  Test infrastructure used only as a baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import zedo_oracle as O
+    from lib.dataset import synthetic as syn
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    n, steps = N_POSES, 16
+    d = syn.make_poses(n, seed=seed)
+    cl = syn.make_clusters(1, seed=seed)
+    cond, K = d["db_2d"][:, :, :2], d["camera_param"]
+    x0 = np.broadcast_to((cl - cl[:, 0:1])[0][None], (n, 17, 3)).astype(np.float32)
+    kl = list(range(17))
+    t0 = time.perf_counter()
+    T0 = O.ipo_init_T(cond, K, 8.0)
+    R, T, _, _, _ = O.ipo_fit(x0[:, kl], T0, K, cond[:, kl], "z", 0.2, 2.0, 500)
+    t_ipo = time.perf_counter() - t0
+    x = np.einsum("bij,bkj->bki", R, x0)
+    conf = O.clamp_conf(d["db_2d"][:, :, 2].copy())
+    ts = O.oil_timestamps(S_OIL)
+    t0 = time.perf_counter()
+    for i in range(steps):   # half with the given T, half with the least-squares T, as in the real loop's mix
+        g, Tn = O.gradient_field_gen(cond, x, K, t=T if i < steps // 5 else None, conf=conf)
+        T = Tn
+        x = O.pc_step(weights, x + g, ts[i])
+    t_step = (time.perf_counter() - t0) / steps
+    gt = d["db_3d"] - d["db_3d"][:, 0:1]
+    t0 = time.perf_counter()
+    O.hypothesis_errors(x[:, None], gt, False)
+    O.hypothesis_errors(x[:, None], gt, True)
+    t_eval = time.perf_counter() - t0
+    per_pose_hyp = (t_ipo + S_OIL * t_step + t_eval) / n
+    return dict(value=1.0 / (N_HYPO * per_pose_hyp), unit="poses/s", cores=int(cores), kind="port",
+                sample=f"numpy oracle, {n} poses x 1 hypothesis: IPO 500 it ({t_ipo:.1f} s) + {steps} of {S_OIL} OIL "
+                       f"steps ({t_step * 1e3:.0f} ms/step) + P1/P2 metric, extrapolated to H={N_HYPO}, S={S_OIL}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--poses", type=int, default=N_POSES, help="poses per GPU (default: BASELINE configs[2])")
+    ap.add_argument("--hypo", type=int, default=N_HYPO)
+    ap.add_argument("--oil", type=int, default=S_OIL)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    import zedo_hip as zh
+    from zedo_hip.pipeline import Pipeline, ZeDOConfig, reduce_min_over_ranks, shard_rows
+    from lib.dataset import synthetic as syn
+
+    # ---- synthetic problem: every rank builds the same global problem, processes its own row shard
+    N_total, H, S = a.poses * world, a.hypo, a.oil
+    weights = syn.make_weights(seed=0)
+    d = syn.make_poses(N_total, seed=2024)
+    clusters = syn.make_clusters(H, seed=2024)
+    cfg = ZeDOConfig.pw3d(OIL_iterations=S)
+    pipe = Pipeline(weights, cfg, dev).load(clusters, d["db_2d"], d["camera_param"])
+    gt = (d["db_3d"] - d["db_3d"][:, 0:1]).astype(np.float64)
+    gt_dev = torch.tensor(gt, dtype=torch.float64, device=dev)
+    lo, rows = shard_rows(H * N_total, rank, world)
+
+    def one_pass():
+        x, T = pipe.run(row_offset=lo, rows=rows)
+        sel = pipe.select(x, gt_dev, row_offset=lo)
+        out = {}
+        for k, (best, idx) in sel.items():
+            out[k] = reduce_min_over_ranks(best, idx)
+        return x, out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_pass()
+    fence()
+    zh.profile_start(sample_every=37, max_samples=4096)   # prime stride: samples all four hidden layers evenly
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        x, out = one_pass()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = zh.profile_stop()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        poses_per_s = N_total * a.steps / dt
+        row_steps_per_s = poses_per_s * H * S
+        hid = prof["hidden_dense"]
+        roof = None
+        if hid["avg_ms"]:
+            flop_launch = 2.0 * rows * 1024 * 1024
+            ach = flop_launch / (hid["avg_ms"] * 1e-3) / 1e12
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC pass, collected separately
+            if os.path.exists(tp):
+                traffic = json.load(open(tp)).get("hidden_dense_bytes_per_launch")
+            roof = dict(bound="mfma", kernel="layer_kernel<128,128,2,2,GN_SILU[_RES]> (1024x1024 dense + GroupNorm + SiLU)",
+                        achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+                        flop_per_launch=flop_launch, avg_launch_ms=round(hid["avg_ms"], 4),
+                        sampled_launches=hid["samples"], launches=hid["launches"])
+        line = {
+            "metric": "poses/sec (1000-step sampler, H=50)", "value": round(poses_per_s, 3), "unit": "poses/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2] shape (3DPW): N={a.poses} poses/GPU x H={H} hypotheses, "
+                                   f"IPO 500 it (17 joints) + {S} OIL steps + P1/P2 min-over-hypotheses selection; "
+                                   "random-init ScoreModelFC_Adv weights, synthetic detections",
+                       "rows_per_gpu": rows, "poses_total": N_total, "sharding": f"rows over {world} rank(s)"},
+            "pose_hyp_steps_per_s": round(row_steps_per_s, 1),
+            "end_to_end_tflops": round(row_steps_per_s * FLOP_PER_ROW_STEP / 1e12, 2),
+            "mpjpe_best_of_H_m": round(float(out["p1"][0].mean().item()), 6),
+            "pa_mpjpe_best_of_H_m": round(float(out["p2"][0].mean().item()), 6),
+            "roofline": roof,
+            "kernel_time_ms_sampled_avg": {k: (round(v["avg_ms"], 4) if v["avg_ms"] else None) for k, v in prof.items()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(weights, None, 2024)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+// Standalone micro-benchmark (no torch): sustained fp32-MFMA peak / shader clock on this box, and the
+// dense-layer kernel variants of zedo_gemm.hip at the BASELINE shape.  Build:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DZEDO_UBENCH tools/ubench/ubench_gemm.hip -o tools/ubench/ubench_gemm
+#include "../../zedo-release_amd/csrc/zedo_gemm.hip"
+#include <cstdio>
+#include <vector>
+#include <random>
+
+using namespace zedo;
+
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float *out, int iters, long long *clk) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f + 1.0f;
+    long long t0 = 0, w0 = 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { t0 = clock64(); w0 = wall_clock64(); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = clock64() - t0; clk[1] = wall_clock64() - w0; }
+    float s = 0;
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+    int M = argc > 1 ? atoi(argv[1]) : 50944;
+    const int N = 1024, K = 1024;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float *dout; long long *dclk; CK(hipMalloc(&dout, 1 << 22)); CK(hipMalloc(&dclk, 16));
+    for (int iters : {2000, 20000, 200000}) {
+        const int blocks = 256 * 2;   // 2 blocks of 4 waves per CU -> 2 waves per SIMD
+        hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, dout, 100, dclk);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, dout, iters, dclk);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        long long clk[2]; CK(hipMemcpy(clk, dclk, 16, hipMemcpyDeviceToHost));
+        double flop = (double)blocks * 4 * iters * 16 * 2.0 * 32 * 32 * 2;
+        printf("mfma peak: iters %7d  %8.3f ms  %7.1f TF   shader clock %.3f GHz (clock64/wall_clock64@100MHz)\n", iters, ms,
+               flop / ms / 1e9, (double)clk[0] / ((double)clk[1] / 100e6) / 1e9);
+    }
+    // ---- GEMM variants
+    std::vector<float> hx((size_t)M * K), hw((size_t)N * K), hb(N), hg(N, 1.f), hbe(N, 0.f);
+    std::mt19937 rng(1); std::uniform_real_distribution<float> u(-1.f, 1.f);
+    for (auto &v : hx) v = u(rng);
+    for (auto &v : hw) v = u(rng) * 0.03f;
+    for (auto &v : hb) v = u(rng);
+    float *dx, *dw, *db, *dg, *dbe, *dy;
+    CK(hipMalloc(&dx, hx.size() * 4)); CK(hipMalloc(&dw, hw.size() * 4)); CK(hipMalloc(&db, N * 4)); CK(hipMalloc(&dg, N * 4));
+    CK(hipMalloc(&dbe, N * 4)); CK(hipMalloc(&dy, hx.size() * 4));
+    CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dg, hg.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dbe, hbe.data(), N * 4, hipMemcpyHostToDevice));
+    LayerArgs a{}; a.X = dx; a.ldx = K; a.W = dw; a.ldw = K; a.bias = db; a.gamma = dg; a.beta = dbe; a.out = dy; a.ldo = N; a.K = K; a.N = N; a.Mp = M;
+    // CPU reference (double) for GN+SiLU on a sample of rows spread over the whole batch
+    std::vector<int> rows;
+    for (int r = 0; r < M; r += 997) rows.push_back(r);
+    for (int r = M - 300; r < M; r += 7) rows.push_back(r);
+    std::vector<double> cref(rows.size() * (size_t)N);
+    for (size_t ri = 0; ri < rows.size(); ++ri) {
+        const float *xr = &hx[(size_t)rows[ri] * K];
+        std::vector<double> v(N);
+        for (int n = 0; n < N; ++n) { double s = hb[n]; const float *wr = &hw[(size_t)n * K]; for (int k = 0; k < K; ++k) s += (double)xr[k] * wr[k]; v[n] = s; }
+        for (int g = 0; g < N / 32; ++g) {
+            double mu = 0, var = 0;
+            for (int c = 0; c < 32; ++c) mu += v[g * 32 + c];
+            mu /= 32;
+            for (int c = 0; c < 32; ++c) var += (v[g * 32 + c] - mu) * (v[g * 32 + c] - mu);
+            var /= 32;
+            for (int c = 0; c < 32; ++c) { double y = (v[g * 32 + c] - mu) / sqrt(var + 1e-5) * hg[g * 32 + c] + hbe[g * 32 + c]; cref[ri * N + g * 32 + c] = y / (1 + exp(-y)); }
+        }
+    }
+    std::vector<float> y((size_t)M * N);
+    for (int var = 0; var < UBENCH_NVAR; ++var) {
+        CK(hipMemset(dy, 0xff, (size_t)M * N * 4));
+        hipError_t e = launch_variant(a, var, 0);
+        if (e != hipSuccess) { printf("variant %d: launch error %s\n", var, hipGetErrorString(e)); continue; }
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(y.data(), dy, y.size() * 4, hipMemcpyDeviceToHost));
+        double maxd = 0; int badrow = -1, nbad = 0;
+        for (size_t ri = 0; ri < rows.size(); ++ri) {
+            double d = 0;
+            for (int n = 0; n < N; ++n) { double dd = fabs((double)y[(size_t)rows[ri] * N + n] - cref[ri * N + n]); if (!(dd <= d)) d = dd; }
+            if (!(d <= 1e-4)) { if (badrow < 0) badrow = rows[ri]; ++nbad; }
+            if (!(d <= maxd)) maxd = d;
+        }
+        const int reps = 100;
+        for (int r = 0; r < 250; ++r) launch_variant(a, var, 0);   // clocks ramp up over ~100 ms: warm up first
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) launch_variant(a, var, 0);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+        printf("variant %2d (%-50s): %7.1f us %6.1f TF  max|y-ref64| %.1e  bad rows %d (first %d)\n", var, variant_name(var), ms * 1e3,
+               2.0 * M * N * K / ms / 1e9, maxd, nbad, badrow);
+    }
+    return 0;
+}

@@ -12,38 +12,113 @@
 //   with 4 runs of 4 consecutive channels -> 16-byte stores into the row-major activation.
 //
 // Both operands are K-contiguous in HBM (torch Linear weight [out][in], activations [row][in]),
-// so both LDS tiles are [rows][BK] and every lane feeds 4 consecutive MFMAs from one
+// so both LDS tiles are [rows][32 floats] and every lane feeds 4 consecutive MFMAs from one
 // ds_read_b128 (lane half kh supplies k = 8*kg + 4*kh + e for MFMA e; A and B agree on that
-// order, so the sum over k is complete).  Row stride BK+4 floats makes the b128 reads and
-// writes bank-conflict free.
+// order, so the sum over k is complete).
 //
-// Pipeline: register-staged global->LDS double buffering, one barrier per 32-wide K tile
-// (4096 MFMA cycles per wave between barriers at the 128x128 tile), 2 workgroups per CU so that
-// one workgroup's epilogue/barrier bubbles hide under the other's MFMAs.
+// What shapes this kernel (measured on MI355X, tools/ubench/ubench_coissue.hip and
+// tools/ubench/ubench_gemm.hip, numbers in DESIGN.md / profiles/):
+//   * v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (64 cycles per instruction per SIMD,
+//     155.9 TFLOP/s sustained) and, while one is pending on a SIMD, VALU and VMEM instructions
+//     of the co-resident waves do not issue (LDS and scalar instructions do).  Every cycle spent
+//     issuing VALU / global-load instructions is therefore lost to the matrix pipe: about 55 cycles
+//     per global_load_dwordx4 with its address add, 40 per ds_write_b128, 6-10 per VALU op.
+//   * Hence tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR destination, no
+//     ds_write pass), per-lane addresses are loop invariant (the K advance is a scalar add), tiles
+//     are as large as the register file allows (256x256 per 8-wave workgroup: 8 DMA instructions
+//     per wave per 128 MFMAs), and the GroupNorm/SiLU epilogue uses v_exp/v_rcp/v_rsq (<= 2 ulp).
+//   * LDS rows are unpadded 128-byte lines (the DMA destination is lane-linear by construction);
+//     bank conflicts are avoided by XOR-swizzling the 16-byte chunk index with (row & 7) on the
+//     SOURCE address and on the fragment read.
+//   * Software pipeline: fragments double-buffered in registers, ONE barrier per 32-wide K tile placed
+//     3/4 through the MFMA burst; tile kt+2 is DMA'd into the buffer of tile kt right after the
+//     barrier that proves every read of tile kt complete, so two LDS buffers suffice.
+//   * 256x256 tiles quantise badly on 256 CUs, so a layer is launched as: 64x128 tiles on the
+//     remainder rows first, then 256x256 tiles on the rows that fill whole rounds (launch_layer).
 #include "zedo_internal.h"
+
+#include <cstdlib>
 
 namespace zedo {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;
+constexpr int BK = 32;   // K depth of one LDS tile (128-byte rows)
 
-__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + expf(-y)); }
+__device__ __forceinline__ float silu_fast(float y) {
+    // y * sigmoid(y) with hardware exp2 / rcp (each <= 1 ulp): |rel err| <= ~3e-7
+    return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.44269504088896340736f));
+}
 
-template <int BM, int BN, int WM, int WN, int EPI>
+// Epilogue for one 32(channel) x 32(row) accumulator tile: lane = (batch row li, channel half kh).
+template <int EPI>
+__device__ __forceinline__ void epilogue_tile(const f32x16 &acc, const f32x4 (&b4)[4], const f32x4 (&ga)[4],
+                                              const f32x4 (&be)[4], float *orow, float sde_a, float sde_c) {
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * g + e] = acc[4 * g + e] + b4[g][e];
+    if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
+        // GroupNorm(32 groups of 32 channels), biased variance, eps 1e-5 (model.py:116,145,150), then SiLU
+        float s = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += v[e];
+        s += __shfl_xor(s, 32);
+        const float mean = s * (1.0f / 32.0f);
+        float qs = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            v[e] -= mean;
+            qs += v[e] * v[e];
+        }
+        qs += __shfl_xor(qs, 32);
+        const float rstd = __builtin_amdgcn_rsqf(qs * (1.0f / 32.0f) + 1e-5f);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = silu_fast(v[4 * g + e] * (rstd * ga[g][e]) + be[g][e]);
+            if constexpr (EPI == EPI_GN_SILU_RES) {   // h = h + h2 (model.py:288), in place
+                const f32x4 h = *reinterpret_cast<const f32x4 *>(orow + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += h[e];
+            }
+            *reinterpret_cast<f32x4 *>(orow + 8 * g) = o;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+            if constexpr (EPI == EPI_SDE) {           // x' = a x + c eps  (sampling.py:185-190 folded)
+                const f32x4 x = *reinterpret_cast<const f32x4 *>(orow + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = sde_a * x[e] + sde_c * v[4 * g + e];
+            } else if constexpr (EPI == EPI_BIAS_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = v[4 * g + e] / (1.0f + expf(-v[4 * g + e]));   // once per schedule: IEEE
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = v[4 * g + e];
+            }
+            *reinterpret_cast<f32x4 *>(orow + 8 * g) = o;
+        }
+    }
+}
+
+// NODMA = 1 (ubench ablation only): skip the in-loop DMA to expose what staging costs.
+template <int BM, int BN, int WM, int WN, int EPI, int NODMA = 0>
 __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
-    constexpr int NT = WM * WN * 64;
+    constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int TJ = TM / 32, TI = TN / 32;
-    constexpr int RPP = NT / 8;  // tile rows covered per pass of 16-byte loads
-    constexpr int LA = BN / RPP, LB = BM / RPP;
-    static_assert(TM % 32 == 0 && TN % 32 == 0 && LA >= 1 && LB >= 1, "tile shape");
+    constexpr int IA = BN / 8 / NW, IB = BM / 8 / NW;   // DMA instructions (8 rows x 128 B each) per wave per tile
+    static_assert(TM % 32 == 0 && TN % 32 == 0 && IA >= 1 && IB >= 1 && (BN / 8) % NW == 0 && (BM / 8) % NW == 0, "tile");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                    // [2][BN][LDS_LD]  W tile
-    float *Bs = smem + 2 * BN * LDS_LD;  // [2][BM][LDS_LD]  X tile
+    float *As = smem;                 // [2][BN][32]  W tile, chunk-swizzled
+    float *Bs = smem + 2 * BN * BK;   // [2][BM][32]  X tile, chunk-swizzled
 
     // XCD-aware, bijective block -> tile map: the hardware places block b on XCD b % 8; give every
     // XCD a contiguous range of tiles so that the column tiles of one row tile share one L2.
@@ -54,15 +129,41 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
     const int m0 = (lid / ncol) * BM, n0 = (lid % ncol) * BN;
 
     const int tid = threadIdx.x;
-    const int chunk = tid & 7, lrow = tid >> 3;
-    const float *Wg = a.W + (size_t)(n0 + lrow) * a.ldw + chunk * 4;
-    const float *Xg = a.X + (size_t)(m0 + lrow) * a.ldx + chunk * 4;
-
-    const int lane = tid & 63, wid = tid >> 6;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN;
     const int li = lane & 31, kh = lane >> 5;
 
-    f32x4 ra[LA], rb[LB];
+    // ---- DMA addressing: instruction p of this wave fills LDS rows [(wid*I + p)*8, +8); lane -> (row, pos);
+    //      LDS position `pos` of a row holds source chunk pos ^ (row & 7)
+    const int drow = lane >> 3, dpos = lane & 7;
+    const float *Wsrc = a.W + (size_t)(n0 + wid * IA * 8 + drow) * a.ldw + (dpos ^ drow) * 4;
+    const float *Xsrc = a.X + (size_t)(m0 + wid * IB * 8 + drow) * a.ldx + (dpos ^ drow) * 4;
+    auto dma = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < IA; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Wsrc + (size_t)p * 8 * a.ldw + kt * BK),
+                                             (__attribute__((address_space(3))) void *)(As + (buf * BN + (wid * IA + p) * 8) * BK), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < IB; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Xsrc + (size_t)p * 8 * a.ldx + kt * BK),
+                                             (__attribute__((address_space(3))) void *)(Bs + (buf * BM + (wid * IB + p) * 8) * BK), 16, 0, 0);
+    };
+
+    // ---- fragment reads: k-chunk c = 2*kg + kh of row i lives at position c ^ (i & 7); tile bases are
+    //      multiples of 8 rows, so i & 7 == li & 7 and the four offsets are loop invariant
+    int foff[4];
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) foff[kg] = ((2 * kg + kh) ^ (li & 7)) * 4;
+    const float *Ab0 = As + (wn * TN + li) * BK;
+    const float *Bb0 = Bs + (wm * TM + li) * BK;
+    f32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
+    auto fread = [&](f32x4(&fa)[TI], f32x4(&fb)[TJ], int buf, int kg) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(Ab0 + (buf * BN + i * 32) * BK + foff[kg]);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(Bb0 + (buf * BM + j * 32) * BK + foff[kg]);
+    };
     f32x16 acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -70,121 +171,72 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    auto gload = [&](int kt) {
+    auto mma = [&](const f32x4(&fa)[TI], const f32x4(&fb)[TJ]) {
 #pragma unroll
-        for (int p = 0; p < LA; ++p) ra[p] = *reinterpret_cast<const f32x4 *>(Wg + (size_t)p * RPP * a.ldw + kt * BK);
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int p = 0; p < LB; ++p) rb[p] = *reinterpret_cast<const f32x4 *>(Xg + (size_t)p * RPP * a.ldx + kt * BK);
-    };
-    auto lstore = [&](int buf) {
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int p = 0; p < LA; ++p)
-            *reinterpret_cast<f32x4 *>(As + (buf * BN + lrow + p * RPP) * LDS_LD + chunk * 4) = ra[p];
-#pragma unroll
-        for (int p = 0; p < LB; ++p)
-            *reinterpret_cast<f32x4 *>(Bs + (buf * BM + lrow + p * RPP) * LDS_LD + chunk * 4) = rb[p];
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     };
 
+    //   iteration kt (tile kt in buffer kt&1; F0 = fragments (kt, kg 0) already in registers):
+    //       F1 = read(kt,1); MFMA(F0);  F0 = read(kt,2); MFMA(F1);  F1 = read(kt,3); MFMA(F0)
+    //       barrier          <- all waves: reads of tile kt complete, DMA of tile kt+1 landed
+    //       DMA(tile kt+2 -> buffer kt&1);  F0 = read(kt+1, 0);  MFMA(F1)
     const int KT = a.K / BK;
-    gload(0);
-    lstore(0);
+    dma(0, 0);
+    dma(KT > 1 ? 1 : 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    fread(fa0, fb0, 0, 0);
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) gload(kt + 1);
-        const float *Ab = As + (buf * BN + wn * TN + li) * LDS_LD + kh * 4;
-        const float *Bb = Bs + (buf * BM + wm * TM + li) * LDS_LD + kh * 4;
-#pragma unroll
-        for (int kg = 0; kg < BK / 8; ++kg) {
-            f32x4 af[TI], bf[TJ];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * LDS_LD + kg * 8);
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * LDS_LD + kg * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < KT) lstore(buf ^ 1);
+        fread(fa1, fb1, buf, 1);
+        mma(fa0, fb0);
+        fread(fa0, fb0, buf, 2);
+        mma(fa1, fb1);
+        fread(fa1, fb1, buf, 3);
+        mma(fa0, fb0);
+        // hipcc (ROCm 7.2) emits only lgkmcnt(0) before this barrier: it does not count the LDS-DMA issued
+        // one iteration ago, so wait for it explicitly (tile kt+1 must have landed in every wave's view).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // Branch-free on purpose (one basic block, so these issue under the MFMAs below): past the last
+        // tile the DMA refills a buffer nobody reads again and the fragment read fetches unused values.
+        if (!NODMA) dma(min(kt + 2, KT - 1), buf);
+        fread(fa0, fb0, buf ^ 1, 0);
+        mma(fa1, fb1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // drain the trailing (unused) DMA before any wave of the workgroup may exit
 
-    // ---------------- epilogue: lane = (batch row j = li, channel half kh) -----------------
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-        const int cbase = n0 + wn * TN + i * 32 + 4 * kh;  // channel of accumulator r: cbase + (r&3) + 8*(r>>2)
+        const int cbase = n0 + wn * TN + i * 32 + 4 * kh;   // channel of accumulator r: cbase + (r&3) + 8*(r>>2)
+        f32x4 b4[4], ga[4], be[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            b4[g] = *reinterpret_cast<const f32x4 *>(a.bias + cbase + 8 * g);
+            if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
+                ga[g] = *reinterpret_cast<const f32x4 *>(a.gamma + cbase + 8 * g);
+                be[g] = *reinterpret_cast<const f32x4 *>(a.beta + cbase + 8 * g);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int m = m0 + wm * TM + j * 32 + li;
-            float *orow = a.out + (size_t)m * a.ldo + cbase;
-            float v[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + cbase + 8 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * g + e] = acc[i][j][4 * g + e] + b4[e];
-            }
-            if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
-                // GroupNorm(32 groups of 32 channels), biased variance, eps 1e-5 (model.py:116,145,150)
-                float s = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) s += v[e];
-                s += __shfl_xor(s, 32);
-                const float mean = s * (1.0f / 32.0f);
-                float qs = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    v[e] -= mean;
-                    qs += v[e] * v[e];
-                }
-                qs += __shfl_xor(qs, 32);
-                const float rstd = 1.0f / sqrtf(qs * (1.0f / 32.0f) + 1e-5f);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 ga = *reinterpret_cast<const f32x4 *>(a.gamma + cbase + 8 * g);
-                    const f32x4 be = *reinterpret_cast<const f32x4 *>(a.beta + cbase + 8 * g);
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = silu_f(v[4 * g + e] * rstd * ga[e] + be[e]);
-                    if constexpr (EPI == EPI_GN_SILU_RES) {
-                        const f32x4 h = *reinterpret_cast<const f32x4 *>(orow + 8 * g);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += h[e];
-                    }
-                    *reinterpret_cast<f32x4 *>(orow + 8 * g) = o;
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 o;
-                    if constexpr (EPI == EPI_SDE) {
-                        const f32x4 x = *reinterpret_cast<const f32x4 *>(orow + 8 * g);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = a.sde_a * x[e] + a.sde_c * v[4 * g + e];
-                    } else if constexpr (EPI == EPI_BIAS_SILU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = silu_f(v[4 * g + e]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = v[4 * g + e];
-                    }
-                    *reinterpret_cast<f32x4 *>(orow + 8 * g) = o;
-                }
-            }
+            epilogue_tile<EPI>(acc[i][j], b4, ga, be, a.out + (size_t)m * a.ldo + cbase, a.sde_a, a.sde_c);
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int NODMA = 0>
 static hipError_t launch_cfg(const LayerArgs &a, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
-    if (a.Mp % BM || a.N % BN || a.K % BK) return hipErrorInvalidValue;
-    auto kern = layer_kernel<BM, BN, WM, WN, EPI>;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+    if (a.Mp <= 0 || a.Mp % BM || a.N % BN || a.K % BK) return hipErrorInvalidValue;
+    auto kern = layer_kernel<BM, BN, WM, WN, EPI, NODMA>;
     static bool attr_done = false;  // per instantiation; benign race (idempotent call)
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -197,6 +249,37 @@ static hipError_t launch_cfg(const LayerArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+static LayerArgs rows_of(const LayerArgs &a, int row0, int rows) {
+    LayerArgs b = a;
+    b.X = a.X + (size_t)row0 * a.ldx;
+    b.out = a.out + (size_t)row0 * a.ldo;
+    b.Mp = rows;
+    return b;
+}
+
+// N == 1024 or 512 (hidden / embedding width): 256x256 tiles on the rows that fill whole rounds of the
+// chip (one 8-wave workgroup per CU), 64x128 tiles (launched first, so that they pack in front) on the rest.
+template <int EPI>
+static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
+    const int per_round = num_cus() * 256 / (a.N / 256);          // rows covered by one full round of 256x256 tiles
+    const int rows_big = (a.Mp / per_round) * per_round;
+    const int rows_small = a.Mp - rows_big;                       // multiple of 256 (ROW_PAD)
+    hipError_t e = hipSuccess;
+    if (rows_small > 0) e = launch_cfg<64, 128, 2, 4, EPI>(rows_of(a, rows_big, rows_small), st);
+    if (e == hipSuccess && rows_big > 0) e = launch_cfg<256, 256, 4, 2, EPI>(rows_of(a, 0, rows_big), st);
+    return e;
+}
+
 hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
     if (a.N == XLD) {  // post_dense: 51 (padded to 64) output channels, one column tile
         switch (epilogue) {
@@ -205,13 +288,45 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
         }
         return hipErrorInvalidValue;
     }
+    if (a.N % 256) return hipErrorInvalidValue;
     switch (epilogue) {
-        case EPI_GN_SILU: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU>(a, st);
-        case EPI_GN_SILU_RES: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES>(a, st);
-        case EPI_BIAS: return launch_cfg<128, 128, 2, 2, EPI_BIAS>(a, st);
-        case EPI_BIAS_SILU: return launch_cfg<128, 128, 2, 2, EPI_BIAS_SILU>(a, st);
+        case EPI_GN_SILU: return launch_wide<EPI_GN_SILU>(a, st);
+        case EPI_GN_SILU_RES: return launch_wide<EPI_GN_SILU_RES>(a, st);
+        case EPI_BIAS: return launch_wide<EPI_BIAS>(a, st);
+        case EPI_BIAS_SILU: return launch_wide<EPI_BIAS_SILU>(a, st);
     }
     return hipErrorInvalidValue;
 }
+
+#ifdef ZEDO_UBENCH
+// ---- variant table for tools/ubench/ubench_gemm.hip ----
+constexpr int UBENCH_NVAR = 8;
+static const char *variant_name(int v) {
+    switch (v) {
+        case 0: return "product launch_layer (256x256 + 64x128 remainder)";
+        case 1: return "128x128 4 waves (2x2)";
+        case 2: return "256x128 8 waves (4x2)";
+        case 3: return "256x256 8 waves (4x2)";
+        case 4: return "256x256 8 waves (2x4)";
+        case 5: return "64x128 8 waves (2x4)";
+        case 6: return "256x256 (4x2), no in-loop DMA [ablation]";
+        case 7: return "product, GN_SILU_RES epilogue";
+    }
+    return "?";
+}
+static hipError_t launch_variant(const LayerArgs &a, int v, hipStream_t st) {
+    switch (v) {
+        case 0: return launch_layer(a, EPI_GN_SILU, st);
+        case 1: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU>(a, st);
+        case 2: return launch_cfg<256, 128, 4, 2, EPI_GN_SILU>(a, st);
+        case 3: return launch_cfg<256, 256, 4, 2, EPI_GN_SILU>(a, st);
+        case 4: return launch_cfg<256, 256, 2, 4, EPI_GN_SILU>(a, st);
+        case 5: return launch_cfg<64, 128, 2, 4, EPI_GN_SILU>(a, st);
+        case 6: return launch_cfg<256, 256, 4, 2, EPI_GN_SILU, 1>(a, st);
+        case 7: return launch_layer(a, EPI_GN_SILU_RES, st);
+    }
+    return hipErrorInvalidValue;
+}
+#endif
 
 }  // namespace zedo

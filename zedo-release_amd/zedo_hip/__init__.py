@@ -116,7 +116,7 @@ class Weights:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and _lib is not None:   # _lib is None during interpreter shutdown
             _lib.zedo_weights_destroy(h)
             self._h = None
 
@@ -144,7 +144,7 @@ class Schedule:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and _lib is not None:
             _lib.zedo_schedule_destroy(h)
             self._h = None
 

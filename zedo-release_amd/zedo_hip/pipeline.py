@@ -1,0 +1,115 @@
+"""Device-resident ZeDO pipeline: the loop of reference run/opt_main.py:166-224 with all H hypotheses
+batched as rows (h, n) and every stage running in libzedo_hip.so.
+
+    ISO  x0[h]   = cluster_h - cluster_h[0]                      (opt_main.py:167-168,173)
+    IPO  (R, T)  = zedo_ipo_fit                                   (opt_main.py:177-195)
+         x       = R x0                                           (opt_main.py:201)
+    OIL  S steps of {reprojection correction, score-network probability-flow step}   (opt_main.py:202-220)
+    selection    = per-pose min over hypotheses of (PA-)MPJPE     (eval_multi)
+
+Rows may be a contiguous shard of the H*N global rows (one shard per GPU); the only exchange is the final
+MIN over ranks, done by the caller (run/opt_main.py, bench.py) with torch.distributed.
+"""
+import numpy as np
+import torch
+
+from . import (Schedule, Weights, ipo_fit, min_mpjpe, oil_run, reproj_prepare, rotate_init)
+
+
+def linspace_f32(start, end, steps):
+    """torch.linspace(start, end, steps) in fp32 without touching a device (opt_main.py:198)."""
+    return torch.linspace(float(start), float(end), int(steps), dtype=torch.float32).numpy()
+
+
+class ZeDOConfig:
+    """The values of configs/optim/concat_pose_optimization_*.py that the path reads."""
+
+    def __init__(self, IPO_iterations=500, IPO_keylist=(0, 1, 4), RotAxes="z", IPO_T=3.0, IPO_minScaleT=0.5,
+                 IPO_maxScaleT=2.0, OIL_iterations=1000, sampling_eps=0.01, sde_T=0.1, num_scales=1000,
+                 beta_min=0.1, beta_max=20.0):
+        self.IPO_iterations, self.IPO_keylist, self.RotAxes = int(IPO_iterations), list(IPO_keylist), RotAxes
+        self.IPO_T, self.IPO_minScaleT, self.IPO_maxScaleT = float(IPO_T), float(IPO_minScaleT), float(IPO_maxScaleT)
+        self.OIL_iterations, self.sampling_eps, self.sde_T = int(OIL_iterations), float(sampling_eps), float(sde_T)
+        self.num_scales, self.beta_min, self.beta_max = int(num_scales), float(beta_min), float(beta_max)
+
+    @classmethod
+    def h36m(cls, **kw):
+        return cls(**kw)
+
+    @classmethod
+    def pw3d(cls, **kw):
+        d = dict(IPO_keylist=tuple(range(17)), IPO_T=8.0, IPO_minScaleT=0.2)
+        d.update(kw)
+        return cls(**d)
+
+
+class Pipeline:
+    def __init__(self, state_dict, cfg, device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            self.weights = state_dict if isinstance(state_dict, Weights) else Weights(state_dict)
+            ts = linspace_f32(cfg.sde_T, cfg.sampling_eps, cfg.OIL_iterations)
+            self.sched = Schedule(self.weights, ts, cfg.beta_min, cfg.beta_max, cfg.num_scales)
+
+    def _dev(self, a, dtype=torch.float32):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=self.device)
+
+    def load(self, sample_poses, db_2d, camera_param):
+        """Upload one problem: clusters [H,17,3], detections [N,17,3]=(u,v,conf), intrinsics [N,3,3]."""
+        sp = self._dev(sample_poses)
+        self.x0 = (sp - sp[:, 0:1, :]).contiguous()             # ISO initial poses, centred on joint 0
+        d2 = self._dev(db_2d)
+        self.uv = d2[:, :, :2].contiguous()
+        self.conf = d2[:, :, 2].contiguous()
+        self.K = self._dev(camera_param)
+        self.H, self.N = self.x0.shape[0], self.uv.shape[0]
+        with torch.cuda.device(self.device):
+            # the reference clamps conf in place inside gradient_field_gen; keep that observable
+            self.geom = reproj_prepare(self.uv, self.K, self.conf, self.conf)
+        return self
+
+    def run(self, row_offset=0, rows=None, oil_steps=None):
+        """IPO + OIL for global rows [row_offset, row_offset+rows) -> (x [rows,17,3], T [rows,3]) on device."""
+        c = self.cfg
+        B = self.H * self.N - row_offset if rows is None else int(rows)
+        S = c.OIL_iterations if oil_steps is None else int(oil_steps)
+        with torch.cuda.device(self.device):
+            R, T = ipo_fit(self.x0, self.uv, self.K, c.IPO_keylist, c.RotAxes, c.IPO_T, c.IPO_minScaleT,
+                           c.IPO_maxScaleT, c.IPO_iterations, self.N * len(c.IPO_keylist) * 2, B, row_offset)
+            x = rotate_init(self.x0, R, self.N, row_offset)
+            oil_run(self.weights, self.sched, x, self.geom, T, 0, S, c.OIL_iterations // 5, row_offset)
+        return x, T
+
+    def select(self, x, gt_centred, row_offset=0):
+        """-> dict(p1=(best[N], idx[N]), p2=(best[N], idx[N])) for the local rows (fp64 / int32 tensors)."""
+        gt = self._dev(gt_centred, torch.float64)
+        with torch.cuda.device(self.device):
+            _, b1, i1 = min_mpjpe(x, gt, self.N, False, row_offset)
+            _, b2, i2 = min_mpjpe(x, gt, self.N, True, row_offset)
+        return dict(p1=(b1, i1), p2=(b2, i2))
+
+
+def reduce_min_over_ranks(best, idx):
+    """The one exchange step of the sharded path: MIN over ranks of the per-pose error (RCCL all-reduce),
+    then the lowest hypothesis index among the ranks that hold that minimum."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return best, idx
+    g = best.clone()
+    dist.all_reduce(g, op=dist.ReduceOp.MIN)
+    cand = torch.where(best == g, idx.to(torch.int64), torch.full_like(idx, 2 ** 31 - 1, dtype=torch.int64))
+    cand = torch.where(idx < 0, torch.full_like(cand, 2 ** 31 - 1), cand)
+    dist.all_reduce(cand, op=dist.ReduceOp.MIN)
+    return g, cand.to(torch.int32)
+
+
+def shard_rows(total_rows, rank, world):
+    """Contiguous, unpadded split of the flattened (h, n) rows (the rule of reference
+    lib/dataset/EvaSampler.py:78-107 applied to rows instead of samples)."""
+    per = -(-total_rows // world)
+    lo = min(rank * per, total_rows)
+    hi = min(lo + per, total_rows)
+    return lo, hi - lo
