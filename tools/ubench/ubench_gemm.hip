@@ -59,6 +59,20 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dg, hg.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dbe, hbe.data(), N * 4, hipMemcpyHostToDevice));
     LayerArgs a{}; a.X = dx; a.ldx = K; a.W = dw; a.ldw = K; a.bias = db; a.gamma = dg; a.beta = dbe; a.out = dy; a.ldo = N; a.K = K; a.N = N; a.Mp = M;
+    if (argc > 2) {   // timeline dump: ubench_gemm M variant out.bin
+        const int var = atoi(argv[2]);
+        long long *dtl; const size_t NWG = (size_t)(M / 64) * 8; CK(hipMalloc(&dtl, NWG * 64)); CK(hipMemset(dtl, 0, NWG * 64));
+        for (int r = 0; r < 300; ++r) launch_variant(a, var, 0);
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &dtl, sizeof(dtl)));
+        launch_variant(a, var, 0);
+        CK(hipDeviceSynchronize());
+        std::vector<long long> tl(NWG * 8);
+        CK(hipMemcpy(tl.data(), dtl, tl.size() * 8, hipMemcpyDeviceToHost));
+        FILE *f = fopen(argc > 3 ? argv[3] : "gpurun_out/wg_timeline.bin", "wb");
+        fwrite(tl.data(), 8, tl.size(), f); fclose(f);
+        printf("timeline of variant %d written\n", var);
+        return 0;
+    }
     // CPU reference (double) for GN+SiLU on a sample of rows spread over the whole batch
     std::vector<int> rows;
     for (int r = 0; r < M; r += 997) rows.push_back(r);

@@ -51,61 +51,50 @@ __device__ __forceinline__ float silu_fast(float y) {
     return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.44269504088896340736f));
 }
 
-// Epilogue for one 32(channel) x 32(row) accumulator tile: lane = (batch row li, channel half kh).
+// Per-element part of the epilogue for one 32(channel) x 32(row) accumulator tile; lane = (batch row li,
+// channel half kh), o[4g+e] belongs to channel cbase + 8g + e.  The residual / previous-x term is added by
+// the caller from the LDS stage (EPI_GN_SILU_RES: o += h;  EPI_SDE: o += sde_a * x).
 template <int EPI>
-__device__ __forceinline__ void epilogue_tile(const f32x16 &acc, const f32x4 (&b4)[4], const f32x4 (&ga)[4],
-                                              const f32x4 (&be)[4], float *orow, float sde_a, float sde_c) {
-    float v[16];
+__device__ __forceinline__ void epilogue_values(const f32x16 &acc, const f32x4 (&b4)[4], const f32x4 (&ga)[4],
+                                                const f32x4 (&be)[4], float sde_c, float (&o)[16]) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * g + e] = acc[4 * g + e] + b4[g][e];
+        for (int e = 0; e < 4; ++e) o[4 * g + e] = acc[4 * g + e] + b4[g][e];
     if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
         // GroupNorm(32 groups of 32 channels), biased variance, eps 1e-5 (model.py:116,145,150), then SiLU
         float s = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s += v[e];
+        for (int e = 0; e < 16; ++e) s += o[e];
         s += __shfl_xor(s, 32);
         const float mean = s * (1.0f / 32.0f);
         float qs = 0.0f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            v[e] -= mean;
-            qs += v[e] * v[e];
+            o[e] -= mean;
+            qs += o[e] * o[e];
         }
         qs += __shfl_xor(qs, 32);
         const float rstd = __builtin_amdgcn_rsqf(qs * (1.0f / 32.0f) + 1e-5f);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 o;
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = silu_fast(v[4 * g + e] * (rstd * ga[g][e]) + be[g][e]);
-            if constexpr (EPI == EPI_GN_SILU_RES) {   // h = h + h2 (model.py:288), in place
-                const f32x4 h = *reinterpret_cast<const f32x4 *>(orow + 8 * g);
+            for (int e = 0; e < 4; ++e) o[4 * g + e] = silu_fast(o[4 * g + e] * (rstd * ga[g][e]) + be[g][e]);
+    } else if constexpr (EPI == EPI_SDE) {            // x' = a x + c eps  (sampling.py:185-190 folded)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += h[e];
-            }
-            *reinterpret_cast<f32x4 *>(orow + 8 * g) = o;
-        }
-    } else {
+        for (int e = 0; e < 16; ++e) o[e] *= sde_c;
+    } else if constexpr (EPI == EPI_BIAS_SILU) {      // built once per schedule: IEEE exp / divide
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 o;
-            if constexpr (EPI == EPI_SDE) {           // x' = a x + c eps  (sampling.py:185-190 folded)
-                const f32x4 x = *reinterpret_cast<const f32x4 *>(orow + 8 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = sde_a * x[e] + sde_c * v[4 * g + e];
-            } else if constexpr (EPI == EPI_BIAS_SILU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = v[4 * g + e] / (1.0f + expf(-v[4 * g + e]));   // once per schedule: IEEE
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = v[4 * g + e];
-            }
-            *reinterpret_cast<f32x4 *>(orow + 8 * g) = o;
-        }
+        for (int e = 0; e < 16; ++e) o[e] = o[e] / (1.0f + expf(-o[e]));
     }
 }
+
+#ifdef ZEDO_UBENCH
+__device__ long long *g_timeline = nullptr;   // ubench only: 8 x int64 per workgroup {t0, t_loop, t_loop_end, t_end, hw_id, xcc_id}
+#define TL_MARK(var) long long var = 0; if (g_timeline && threadIdx.x == 0) var = wall_clock64();
+#else
+#define TL_MARK(var)
+#endif
 
 // NODMA = 1 (ubench ablation only): skip the in-loop DMA to expose what staging costs.
 template <int BM, int BN, int WM, int WN, int EPI, int NODMA = 0>
@@ -119,6 +108,7 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                 // [2][BN][32]  W tile, chunk-swizzled
     float *Bs = smem + 2 * BN * BK;   // [2][BM][32]  X tile, chunk-swizzled
+    float *Ps = smem + 2 * (BM + BN) * BK;   // [3][BN]  bias | gamma | beta of this tile's channels (epilogue)
 
     // XCD-aware, bijective block -> tile map: the hardware places block b on XCD b % 8; give every
     // XCD a contiguous range of tiles so that the column tiles of one row tile share one L2.
@@ -185,12 +175,22 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
     //       F1 = read(kt,1); MFMA(F0);  F0 = read(kt,2); MFMA(F1);  F1 = read(kt,3); MFMA(F0)
     //       barrier          <- all waves: reads of tile kt complete, DMA of tile kt+1 landed
     //       DMA(tile kt+2 -> buffer kt&1);  F0 = read(kt+1, 0);  MFMA(F1)
+    TL_MARK(tl0)
+    // epilogue parameters -> LDS once (LDS reads are free next to MFMAs, VMEM loads are not)
+    if (tid < BN / 4) {
+        *reinterpret_cast<f32x4 *>(Ps + tid * 4) = *reinterpret_cast<const f32x4 *>(a.bias + n0 + tid * 4);
+        if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
+            *reinterpret_cast<f32x4 *>(Ps + BN + tid * 4) = *reinterpret_cast<const f32x4 *>(a.gamma + n0 + tid * 4);
+            *reinterpret_cast<f32x4 *>(Ps + 2 * BN + tid * 4) = *reinterpret_cast<const f32x4 *>(a.beta + n0 + tid * 4);
+        }
+    }
     const int KT = a.K / BK;
     dma(0, 0);
     dma(KT > 1 ? 1 : 0, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     fread(fa0, fb0, 0, 0);
+    TL_MARK(tl1)
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         fread(fa1, fb1, buf, 1);
@@ -211,30 +211,101 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // drain the trailing (unused) DMA before any wave of the workgroup may exit
+    TL_MARK(tl2)
 
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int cbase = n0 + wn * TN + i * 32 + 4 * kh;   // channel of accumulator r: cbase + (r&3) + 8*(r>>2)
-        f32x4 b4[4], ga[4], be[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            b4[g] = *reinterpret_cast<const f32x4 *>(a.bias + cbase + 8 * g);
-            if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
-                ga[g] = *reinterpret_cast<const f32x4 *>(a.gamma + cbase + 8 * g);
-                be[g] = *reinterpret_cast<const f32x4 *>(a.beta + cbase + 8 * g);
-            }
-        }
+    // ---------------- epilogue: all global traffic goes through the (now free) LDS as 1 KB wave accesses ----
+    // Direct stores from the accumulator layout would be 16 bytes per lane at a 4 KB row stride: 4x the VMEM
+    // instructions, and VMEM issue time is matrix-pipe time for the next workgroup's MFMAs (see header).
+    // Phase j stages rows {wm*TM + j*32 + li} x BN channels; 16-byte chunk c of stage row sr sits at position
+    // c ^ (sr & 7), which makes the per-lane ds_write_b128 and the row-wise read-out both conflict free and
+    // lets the residual (EPI_GN_SILU_RES: h, EPI_SDE: x) arrive by LDS-DMA in the same layout.
+    {
+        constexpr int NT = NW * 64;
+        constexpr int SR = WM * 32;          // stage rows per phase
+        constexpr int CPRW = BN / 4;         // 16-byte chunks per stage row
+        constexpr int RPI = 64 / CPRW;       // stage rows filled by one DMA instruction
+        static_assert(CPRW <= 64 && 64 % CPRW == 0 && SR % (RPI * NW) == 0 && (SR * CPRW) % NT == 0, "stage shape");
+        static_assert((size_t)SR * BN <= (size_t)2 * (BM + BN) * BK, "stage must fit in the tile buffers");
+        constexpr bool HAS_RES = (EPI == EPI_GN_SILU_RES || EPI == EPI_SDE);
+        float *S = smem;
+        float *obase = a.out + (size_t)m0 * a.ldo + n0;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-            const int m = m0 + wm * TM + j * 32 + li;
-            epilogue_tile<EPI>(acc[i][j], b4, ga, be, a.out + (size_t)m * a.ldo + cbase, a.sde_a, a.sde_c);
+            if constexpr (HAS_RES) {
+                constexpr int NI = SR / RPI / NW;   // DMA instructions per wave
+#pragma unroll
+                for (int p = 0; p < NI; ++p) {
+                    const int idx = wid * NI + p;                         // wave-uniform
+                    const int sr = idx * RPI + lane / CPRW, pos = lane % CPRW;
+                    const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(obase + (size_t)grow * a.ldo + (pos ^ (sr & 7)) * 4),
+                        (__attribute__((address_space(3))) void *)(S + idx * RPI * BN), 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                float o[16];
+                f32x4 b4[4], ga[4], be[4];
+                const float *pc = Ps + wn * TN + i * 32 + 4 * kh;   // channel of accumulator r: + (r&3) + 8*(r>>2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    b4[g] = *reinterpret_cast<const f32x4 *>(pc + 8 * g);
+                    if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
+                        ga[g] = *reinterpret_cast<const f32x4 *>(pc + BN + 8 * g);
+                        be[g] = *reinterpret_cast<const f32x4 *>(pc + 2 * BN + 8 * g);
+                    }
+                }
+                epilogue_values<EPI>(acc[i][j], b4, ga, be, a.sde_c, o);
+                float *srow = S + (wm * 32 + li) * BN;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = (wn * TN + i * 32 + 8 * g + 4 * kh) >> 2;
+                    f32x4 *slot = reinterpret_cast<f32x4 *>(srow + ((c ^ (li & 7)) << 2));
+                    f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+                    if constexpr (EPI == EPI_GN_SILU_RES) {          // h = h + h2 (model.py:288)
+                        const f32x4 h = *slot;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += h[e];
+                    } else if constexpr (EPI == EPI_SDE) {
+                        const f32x4 x = *slot;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += a.sde_a * x[e];
+                    }
+                    *slot = v;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int pass = 0; pass < SR * CPRW / NT; ++pass) {
+                const int qi = pass * NT + tid;
+                const int sr = qi / CPRW, c = qi % CPRW;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(S + sr * BN + ((c ^ (sr & 7)) << 2));
+                const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
+                *reinterpret_cast<f32x4 *>(obase + (size_t)grow * a.ldo + c * 4) = v;
+            }
+            if (j + 1 < TJ) __syncthreads();
         }
     }
+#ifdef ZEDO_UBENCH
+    if (g_timeline) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store tail of this wave
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long *d = g_timeline + (size_t)blockIdx.x * 8;
+            d[0] = tl0; d[1] = tl1; d[2] = tl2; d[3] = wall_clock64();
+            d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+            d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        }
+    }
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int NODMA = 0>
 static hipError_t launch_cfg(const LayerArgs &a, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+    constexpr size_t lds = ((size_t)2 * (BM + BN) * BK + 3 * BN) * sizeof(float);
     if (a.Mp <= 0 || a.Mp % BM || a.N % BN || a.K % BK) return hipErrorInvalidValue;
     auto kern = layer_kernel<BM, BN, WM, WN, EPI, NODMA>;
     static bool attr_done = false;  // per instantiation; benign race (idempotent call)
