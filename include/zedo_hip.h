@@ -69,10 +69,13 @@ void zedo_weights_destroy(zedo_weights_t *w);
  *   a[s], c[s]     with  x' = a x + c eps_theta(x, 999 t)  == EulerMaruyamaPredictor.update_fn on
  *                    the probability-flow reverse sub-VP SDE with dt = -1/n_sde
  *                    (advanced/sampling.py:185-191, sde_lib.py:93-100,187-198, utils.py:751-777).
+ * label_scale: the network is evaluated at labels = h_t * label_scale (fp32 product).  Pass 999 with
+ * h_t = SDE times t (utils.py:762), or 1 with h_t = labels when calling the model surface directly
+ * (then a, c are computed at t = label/999).
  * Synchronises `stream` before returning.
  */
-int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, int S, float beta_min, float beta_max,
-                         int n_sde, void *stream, zedo_schedule_t **out);
+int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, int S, float label_scale, float beta_min,
+                         float beta_max, int n_sde, void *stream, zedo_schedule_t **out);
 void zedo_schedule_destroy(zedo_schedule_t *s);
 /* debug/parity accessors: copy tables to host (synchronise). tbias: [S][1+2*n_blocks][H]. */
 int zedo_schedule_read(const zedo_schedule_t *s, float *h_tbias, float *h_a, float *h_c);

@@ -1,0 +1,156 @@
+"""CPU tests of the host-side mirror of the reference's callable surface (no GPU, no HIP calls)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import zedo_oracle as O
+
+
+def cfg_path(name):
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zedo-release_amd", "configs",
+                        "optim", f"concat_pose_optimization_{name}.py")
+
+
+def test_module_paths_of_the_reference_exist():
+    import lib.sampling                                     # noqa: F401  (BASELINE.json names lib/sampling.py)
+    from lib.algorithms.advanced import sampling, sde_lib, utils, model, simple_zeroshot_opt  # noqa: F401
+    from lib.algorithms.ema import ExponentialMovingAverage   # noqa: F401
+    from lib.dataset.h36m import H36MDataset3D                # noqa: F401
+    from lib.dataset.pw3d import PW3D                          # noqa: F401
+    from lib.dataset.custom import CustomDataset               # noqa: F401
+    from lib.utils.transforms import procrustes, align_to_gt   # noqa: F401
+    import run.opt_main
+    import run.inference
+    for m in (run.opt_main, run.inference):
+        assert callable(m.parse_args) and callable(m.main)
+    assert sorted(sampling._PREDICTORS) == ["euler_maruyama", "none", "reverse_diffusion"]
+    assert sorted(sampling._CORRECTORS) == ["langevin", "none"]
+
+
+def test_configs_hold_the_reference_values():
+    from run._driver import load_config
+    h, p, w = (load_config(cfg_path(n)) for n in ("h36m", "pw3d", "wild"))
+    for c in (h, p, w):
+        assert c.training.sde == "subvpsde" and c.sampling.method == "pc"
+        assert c.sampling.predictor == "euler_maruyama" and c.sampling.corrector == "none"
+        assert c.model.t == 0.1 and c.model.beta_min == 0.1 and c.model.beta_max == 20.0 and c.model.num_scales == 1000
+        assert c.ZeDO.IPO_iterations == 500 and c.ZeDO.OIL_iterations == 1000 and c.ZeDO.sampling_eps == 0.01
+        assert c.sampling.noise_removal is True
+    assert (h.ZeDO.IPO_keylist, h.ZeDO.IPO_T, h.ZeDO.IPO_minScaleT, h.ZeDO.sample, h.ZeDO.batch) == ([0, 1, 4], 3, 0.5, 640, 886)
+    assert (p.ZeDO.IPO_keylist, p.ZeDO.IPO_T, p.ZeDO.IPO_minScaleT, p.ZeDO.sample, p.ZeDO.batch) == (list(range(17)), 8, 0.2, 35, 1015)
+    assert (h.data.dataset, p.data.dataset, w.data.dataset) == ("h36m", "3dpw", "wild")
+
+
+def test_flags_match_the_reference():
+    import run.opt_main as om
+    import run.inference as inf
+    a = om.parse_args(["prog", "--config", "c.py", "--ckpt_dir", "d", "--ckpt_name", "f", "--hypo", "50", "--gt"])
+    assert (a.config, a.ckpt_dir, a.ckpt_name, a.hypo, a.gt) == ("c.py", "d", "f", 50, True)
+    b = inf.parse_args(["prog", "--config", "c.py", "--eval"])
+    assert b.eval is True and b.hypo == 1 and b.gt is False
+
+
+def test_subvpsde_matches_oracle():
+    from lib.algorithms.advanced import sde_lib
+    sde = sde_lib.subVPSDE(beta_min=0.1, beta_max=20.0, N=1000, T=0.1)
+    assert sde.T == 0.1 and sde.N == 1000
+    x = torch.randn(5, 17, 3)
+    for t in (0.1, 0.0555, 0.01):
+        vt = torch.ones(5) * t
+        drift, diff = sde.sde(x, vt)
+        d_ref, g_ref = O.subvp_sde(x.numpy(), np.float32(t))
+        np.testing.assert_allclose(drift.numpy(), d_ref, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(diff.numpy(), np.full(5, g_ref), rtol=3e-5)   # 1 - exp(-small): cancellation
+        mean, std = sde.marginal_prob(x, vt)
+        np.testing.assert_allclose(std.numpy(), np.full(5, O.subvp_marginal_std(np.float32(t))), rtol=3e-5)
+    # reverse(): probability-flow drift with a fake score; diffusion zeroed
+    rs = sde.reverse(lambda x, t, c, m: torch.ones_like(x), probability_flow=True)
+    drift, diff = rs.sde(x, torch.ones(5) * 0.05, None, None)
+    f, g = sde.sde(x, torch.ones(5) * 0.05)
+    np.testing.assert_allclose(drift.numpy(), (f - g[:, None, None] ** 2).numpy(), rtol=1e-6)
+    assert diff.shape == (1,) and float(diff) == 0.0 and rs.N == 1000 and rs.T == 0.1
+
+
+def test_model_state_dict_layout_and_checkpoint_loading(weights0):
+    from lib.algorithms.advanced.model import ScoreModelFC_Adv, get_timestep_embedding
+    from lib.dataset import synthetic as syn
+    from run._driver import load_config
+    m = ScoreModelFC_Adv(load_config(cfg_path("h36m")), 17, 3, 1024, 512, 3)
+    keys = list(m.state_dict().keys())
+    assert keys[0] == "sigmas" and keys[1:] == [n for n, _ in syn.state_dict_layout()]
+    assert m.state_dict()["sigmas"].dtype == torch.float64 and m.state_dict()["sigmas"].shape == (1000,)
+    sd = {k: torch.tensor(v) for k, v in weights0.items()}
+    sd["sigmas"] = torch.tensor(syn.sigmas_buffer())
+    # a DataParallel checkpoint as the reference strips it (run/opt_main.py:130-132)
+    wrapped = {"module." + k: v for k, v in sd.items()}
+    m.load_state_dict({k[7:]: v for k, v in wrapped.items()}, strict=True)
+    assert torch.equal(m.post_dense.weight, sd["post_dense.weight"])
+    pe = get_timestep_embedding(torch.tensor([99.9, 10.0]), 512).numpy()
+    np.testing.assert_allclose(pe, O.timestep_embedding(np.array([99.9, 10.0], np.float32), 512), atol=5e-5)
+    m.train()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 17, 3), torch.ones(2), None, None)
+
+
+def test_rotopt_forward_and_quaternion(golden):
+    from lib.algorithms.advanced.simple_zeroshot_opt import RotOpt, perpendicular_distance
+    from lib.algorithms.advanced.utils import quaternion_to_matrix
+    q = torch.randn(6, 4)
+    np.testing.assert_allclose(quaternion_to_matrix(q).numpy(), O.quaternion_to_matrix(q.numpy()), atol=1e-6)
+    g = golden("ipo")
+    N = 8
+    cond, K = g[f"db2d_{N}"][:, :, :2], g[f"K_{N}"]
+    ro = RotOpt(N, axis="xyz", minT=0.5, maxT=2)
+    assert sorted(n for n, _ in ro.named_parameters()) == ["identity", "rot_vect", "rot_vect_x", "rot_vect_y", "rot_vect_z", "scale"]
+    with torch.no_grad():
+        ro.rot_vect.copy_(torch.tensor(g[f"trace_q_{N}_xyz_h36m"][19][:, 0:1]))
+        for i, a in enumerate("xyz"):
+            getattr(ro, f"rot_vect_{a}").copy_(torch.tensor(g[f"trace_q_{N}_xyz_h36m"][19][:, i + 1:i + 2]))
+        ro.scale.copy_(torch.tensor(g[f"trace_scale_{N}_xyz_h36m"][19]).reshape(-1, 1, 1))
+    kl = [0, 1, 4]
+    x0 = np.broadcast_to(g["cluster0"][None], (N, 17, 3)).astype(np.float32)
+    T0 = g[f"T0_{N}_xyz_h36m"]
+    uv = ro(torch.tensor(x0[:, kl]), torch.tensor(T0), torch.tensor(K)).detach().numpy()
+    _, _, _, uv_ref = O.ipo_loss_and_grads(ro.quaternion().detach().numpy(), ro.scale.detach().numpy().reshape(-1),
+                                           x0[:, kl], T0.reshape(N, 3), K, cond[:, kl], "xyz", 0.5, 2.0, N * 6)
+    np.testing.assert_allclose(uv, uv_ref, rtol=1e-5, atol=1e-3)
+    p, v = torch.randn(3, 17, 3), torch.nn.functional.normalize(torch.randn(3, 17, 3), dim=-1)
+    assert torch.allclose((perpendicular_distance(p, v) * v).sum(-1), torch.zeros(3, 17), atol=1e-5)
+
+
+def test_ema_roundtrip():
+    from lib.algorithms.ema import ExponentialMovingAverage
+    lin = torch.nn.Linear(4, 3)
+    ema = ExponentialMovingAverage(lin.parameters(), decay=0.9999)
+    with torch.no_grad():
+        lin.weight.add_(1.0)
+    ema.update(lin.parameters())
+    sd = ema.state_dict()
+    assert set(sd) == {"decay", "num_updates", "shadow_params"} and sd["num_updates"] == 1
+    ema2 = ExponentialMovingAverage(torch.nn.Linear(4, 3).parameters(), decay=0.5)
+    ema2.load_state_dict(sd)
+    assert ema2.decay == 0.9999 and torch.equal(ema2.shadow_params[0], ema.shadow_params[0])
+
+
+def test_procrustes_host_helper(golden):
+    from lib.utils.transforms import align_to_gt, procrustes
+    g = golden("eval_multi")
+    gt = (g["gt_mm_h36m"] - g["gt_mm_h36m"][:, 0:1]) / 1000.0
+    for n, h in ((0, 0), (4, 3), (7, 2)):      # (4,3) is a mirrored hypothesis: 'best' allows the reflection
+        Z = align_to_gt(pose=g["preds"][n, h], pose_gt=gt[n])
+        np.testing.assert_allclose(Z, g["aligned"][n, h], atol=5e-7)
+    d, Z, tf = procrustes(gt[0], g["preds"][0, 0], reflection=False)
+    assert np.linalg.det(tf["rotation"]) > 0
+
+
+def test_shard_rows_is_a_contiguous_unpadded_partition():
+    from zedo_hip.pipeline import linspace_f32, shard_rows
+    for total, world in ((50 * 1015, 8), (50 * 1015, 3), (7, 8), (886, 2)):
+        parts = [shard_rows(total, r, world) for r in range(world)]
+        assert parts[0][0] == 0 and sum(n for _, n in parts) == total
+        for (lo, n), (lo2, _) in zip(parts, parts[1:]):
+            assert lo + n == lo2
+    assert np.array_equal(linspace_f32(0.1, 0.01, 1000), O.oil_timestamps(1000))
+    assert np.array_equal(linspace_f32(0.1, 0.01, 100), O.oil_timestamps(100))

@@ -207,9 +207,9 @@ extern "C" void zedo_weights_destroy(zedo_weights_t *w) {
     delete w;
 }
 
-extern "C" int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, int S, float beta_min, float beta_max,
-                                    int n_sde, void *stream, zedo_schedule_t **out) {
-    if (!w || !h_t || !out || S < 1 || n_sde < 1) return ZEDO_E_BADARG;
+extern "C" int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, int S, float label_scale, float beta_min,
+                                    float beta_max, int n_sde, void *stream, zedo_schedule_t **out) {
+    if (!w || !h_t || !out || S < 1 || n_sde < 1 || !(label_scale > 0.f)) return ZEDO_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const int Sp = round_up(S, ROW_PAD);
     zedo_schedule *s = new (std::nothrow) zedo_schedule();
@@ -219,7 +219,7 @@ extern "C" int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, i
     // x' = x + drift*dt, drift = -beta/2 x - beta*disc*score, score = -eps/std, dt = -1/n_sde
     //   => a = 1 + beta/(2 n_sde),  c = -beta*disc/(n_sde*std)      (sde_lib.py:187-198, sampling.py:185-190)
     for (int i = 0; i < S; ++i) {
-        const double t = (double)h_t[i], b0 = (double)beta_min, b1 = (double)beta_max;
+        const double t = (double)h_t[i] * ((double)label_scale / 999.0), b0 = (double)beta_min, b1 = (double)beta_max;
         const double beta = b0 + t * (b1 - b0);
         const double disc = 1.0 - std::exp(-2.0 * b0 * t - (b1 - b0) * t * t);
         const double sd = 1.0 - std::exp(2.0 * (-0.25 * t * t * (b1 - b0) - 0.5 * t * b0));
@@ -233,7 +233,7 @@ extern "C" int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, i
     if (e == hipSuccess) e = hipMalloc(&d_temb, sizeof(float) * (size_t)Sp * EMB);
     if (e == hipSuccess) e = hipMalloc(&s->d_tbias, sizeof(float) * (size_t)Sp * NLAYER * HID);
     if (e == hipSuccess) e = hipMemcpyAsync(d_t, h_t, sizeof(float) * S, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = launch_posemb(d_t, S, Sp, d_pe, st);
+    if (e == hipSuccess) e = launch_posemb(d_t, S, Sp, label_scale, d_pe, st);
     if (e == hipSuccess) {
         // temb = SiLU(W_s pe + b_s)   (model.py:128-131,259)
         LayerArgs a{};

@@ -346,6 +346,9 @@ static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
     const int rows_big = (a.Mp / per_round) * per_round;
     const int rows_small = a.Mp - rows_big;                       // multiple of 256 (ROW_PAD)
     hipError_t e = hipSuccess;
+    // K <= 64 (pre_dense): almost no MFMA work per output, the layer is bound by writing the activation:
+    // many small co-resident workgroups overlap their stores, one big tile per CU cannot.
+    if (a.K <= 64) return launch_cfg<64, 128, 2, 4, EPI>(a, st);
     if (rows_small > 0) e = launch_cfg<64, 128, 2, 4, EPI>(rows_of(a, rows_big, rows_small), st);
     if (e == hipSuccess && rows_big > 0) e = launch_cfg<256, 256, 4, 2, EPI>(rows_of(a, 0, rows_big), st);
     return e;

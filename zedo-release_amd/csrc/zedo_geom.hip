@@ -228,7 +228,7 @@ hipError_t launch_reproj_step_padded(float *xpad, const float *geom, float *T, i
 // ------------------------------------------------------------------------------------------
 // sinusoidal timestep embedding (model.py:81-95) for labels = 999 t  (utils.py:762)
 // ------------------------------------------------------------------------------------------
-__global__ void posemb_kernel(const float *__restrict__ t, int S, int Sp, float *__restrict__ pe) {
+__global__ void posemb_kernel(const float *__restrict__ t, int S, int Sp, float label_scale, float *__restrict__ pe) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Sp * EMB) return;
     const int s = i / EMB, c = i % EMB;
@@ -238,15 +238,15 @@ __global__ void posemb_kernel(const float *__restrict__ t, int S, int Sp, float 
         const float emb = (float)(-9.210340371976184 / (half - 1));  // -log(10000)/(half-1), rounded like the fp32 mul
         const int k = c < half ? c : c - half;
         const float freq = expf((float)k * emb);
-        const float arg = (t[s] * 999.0f) * freq;
+        const float arg = (t[s] * label_scale) * freq;
         o = c < half ? sinf(arg) : cosf(arg);
     }
     pe[i] = o;
 }
 
-hipError_t launch_posemb(const float *t, int S, int Sp, float *pe, hipStream_t st) {
+hipError_t launch_posemb(const float *t, int S, int Sp, float label_scale, float *pe, hipStream_t st) {
     const int n = Sp * EMB;
-    hipLaunchKernelGGL(posemb_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t, S, Sp, pe);
+    hipLaunchKernelGGL(posemb_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t, S, Sp, label_scale, pe);
     return hipGetLastError();
 }
 

@@ -1,0 +1,187 @@
+"""Samplers of the drop-in surface (reference lib/algorithms/advanced/sampling.py).
+
+`get_sampling_fn(config, sde, shape, inverse_scaler, eps, device)` returns `pc_sampler` with the reference's
+signature and return types: `(trajs np.ndarray[1,B,J,3], x_mean np.ndarray[B,J,3])` (:450-527).
+
+Fast path = the shipped configuration (configs/optim/*.py: method 'pc', predictor 'euler_maruyama',
+corrector 'none', probability_flow forced True at run/opt_main.py:157, sub-VP SDE): the whole call is one
+`zedo_sde_step` - x' = a_t x + c_t eps(x, 999 t) - on the device.  Other registered predictor / corrector
+combinations run the generic update rules below around the HIP score function.  The fused driver
+(run/opt_main.py) does not go through this per-step surface at all; it exists so that callers of the
+reference's sampling_fn keep working.
+"""
+import functools
+
+import numpy as np
+import torch
+
+from . import sde_lib
+from . import utils as mutils
+from .utils import from_flattened_numpy, to_flattened_numpy, get_score_fn  # noqa: F401  (re-exported like the reference)
+
+_PREDICTORS, _CORRECTORS = {}, {}
+
+
+def _registrar(table, cls, name):
+    def deco(c):
+        key = name or c.__name__
+        if key in table:
+            raise ValueError(f"Already registered model with name: {key}")
+        table[key] = c
+        return c
+    return deco if cls is None else deco(cls)
+
+
+def register_predictor(cls=None, *, name=None):
+    return _registrar(_PREDICTORS, cls, name)
+
+
+def register_corrector(cls=None, *, name=None):
+    return _registrar(_CORRECTORS, cls, name)
+
+
+def get_predictor(name):
+    return _PREDICTORS[name]
+
+
+def get_corrector(name):
+    return _CORRECTORS[name]
+
+
+class Predictor:
+    def __init__(self, sde, score_fn, probability_flow=False):
+        self.sde, self.score_fn = sde, score_fn
+        self.rsde = sde.reverse(score_fn, probability_flow)
+
+    def update_fn(self, x, t, condition, mask):
+        raise NotImplementedError
+
+
+class Corrector:
+    def __init__(self, sde, score_fn, snr, n_steps):
+        self.sde, self.score_fn, self.snr, self.n_steps = sde, score_fn, snr, n_steps
+
+    def update_fn(self, x, t, condition, mask):
+        raise NotImplementedError
+
+
+@register_predictor(name="euler_maruyama")
+class EulerMaruyamaPredictor(Predictor):
+    """x_mean = x + drift * (-1/N); x = x_mean + diffusion sqrt(1/N) z   (reference :180-191)"""
+
+    def update_fn(self, x, t, condition, mask):
+        dt = -1.0 / self.rsde.N
+        drift, diffusion = self.rsde.sde(x, t, condition, mask)
+        x_mean = x + drift * dt
+        x = x_mean + diffusion[:, None, None] * np.sqrt(-dt) * torch.randn_like(x)
+        return x, x_mean
+
+
+@register_predictor(name="reverse_diffusion")
+class ReverseDiffusionPredictor(Predictor):
+    def update_fn(self, x, t, condition, mask):
+        f, G = self.rsde.discretize(x, t, condition, mask)
+        x_mean = x - f
+        return x_mean + G[:, None, None] * torch.randn_like(x), x_mean
+
+
+@register_predictor(name="none")
+class NonePredictor(Predictor):
+    def __init__(self, sde, score_fn, probability_flow=False):
+        pass
+
+    def update_fn(self, x, t, condition, mask):
+        return x, x
+
+
+@register_corrector(name="none")
+class NoneCorrector(Corrector):
+    def __init__(self, sde, score_fn, snr, n_steps):
+        pass
+
+    def update_fn(self, x, t, condition, mask):
+        return x, x
+
+
+@register_corrector(name="langevin")
+class LangevinCorrector(Corrector):
+    def update_fn(self, x, t, condition, mask):
+        sde = self.sde
+        if isinstance(sde, sde_lib.VPSDE):
+            alpha = sde.alphas.to(t.device)[(t * (sde.N - 1) / sde.T).long()]
+        else:
+            alpha = torch.ones_like(t)
+        x_mean = x
+        for _ in range(self.n_steps):
+            grad = self.score_fn(x, t, condition, mask)
+            noise = torch.randn_like(x)
+            gn = torch.norm(grad.reshape(grad.shape[0], -1), dim=-1).mean()
+            nn_ = torch.norm(noise.reshape(noise.shape[0], -1), dim=-1).mean()
+            step = (self.snr * nn_ / gn) ** 2 * 2 * alpha
+            x_mean = x + step[:, None, None] * grad
+            x = x_mean + torch.sqrt(step * 2)[:, None, None] * noise
+        return x, x_mean
+
+
+def shared_predictor_update_fn(x, t, condition, mask, sde, model, predictor, probability_flow, continuous):
+    score_fn = mutils.get_score_fn(sde, model, train=False, continuous=continuous)
+    obj = NonePredictor(sde, score_fn, probability_flow) if predictor is None else predictor(sde, score_fn, probability_flow)
+    return obj.update_fn(x, t, condition, mask)
+
+
+def shared_corrector_update_fn(x, t, condition, mask, sde, model, corrector, continuous, snr, n_steps):
+    score_fn = mutils.get_score_fn(sde, model, train=False, continuous=continuous)
+    obj = NoneCorrector(sde, score_fn, snr, n_steps) if corrector is None else corrector(sde, score_fn, snr, n_steps)
+    return obj.update_fn(x, t, condition, mask)
+
+
+def get_sampling_fn(config, sde, shape, inverse_scaler, eps, device=None):
+    """reference :80-127"""
+    device = config.device if device is None else device
+    name = config.sampling.method.lower()
+    if name != "pc":
+        raise NotImplementedError(f"sampler '{name}': the reference's ODE sampler is broken as shipped "
+                                  "(SURVEY.md 2, row 4); only 'pc' is provided")
+    return get_pc_sampler(sde=sde, shape=shape,
+                          predictor=get_predictor(config.sampling.predictor.lower()),
+                          corrector=get_corrector(config.sampling.corrector.lower()),
+                          inverse_scaler=inverse_scaler, snr=config.sampling.snr,
+                          n_steps=config.sampling.n_steps_each, probability_flow=config.sampling.probability_flow,
+                          continuous=config.training.continuous, denoise=config.sampling.noise_removal,
+                          eps=eps, device=device)
+
+
+def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps=1, probability_flow=False,
+                   continuous=False, denoise=True, eps=1e-3, device="cuda"):
+    """One predictor-corrector step per call (reference :400-529)."""
+    fused = (predictor is EulerMaruyamaPredictor and corrector is NoneCorrector and probability_flow
+             and isinstance(sde, sde_lib.subVPSDE))
+    pred_fn = functools.partial(shared_predictor_update_fn, sde=sde, predictor=predictor,
+                                probability_flow=probability_flow, continuous=continuous)
+    corr_fn = functools.partial(shared_corrector_update_fn, sde=sde, corrector=corrector, continuous=continuous,
+                                snr=snr, n_steps=n_steps)
+
+    def pc_sampler(model, condition, gradient=None, denoise_x=None, t=None, t_step=None, args=None):
+        with torch.no_grad():
+            x = denoise_x
+            tval = float(t)
+            if t_step is not None and t_step < 0:      # reference :499 (disabled override, kept for parity)
+                tval = 1.0
+            if fused:
+                import zedo_hip
+                model.eval()
+                sched = model.hip_schedule([tval], 999.0, sde.beta_0, sde.beta_1, sde.N)
+                x_mean = x.detach().float().contiguous().clone()
+                zedo_hip.sde_step(model.hip_weights(), sched, 0, x_mean)
+                x_new = x_mean                            # diffusion is zero for the probability-flow ODE
+            else:
+                vec_t = torch.ones(x.shape[0], device=x.device) * tval
+                mask = torch.zeros_like(x)
+                x1, _ = corr_fn(x, vec_t, condition, mask, model=model)
+                x_new, x_mean = pred_fn(x1, vec_t, condition, mask, model=model)
+            trajs = np.stack([x_new.cpu().numpy()], axis=0)
+            x_mean_np = x_mean.cpu().numpy()
+            trajs[-1] = x_mean_np
+            return trajs, (x_mean_np if denoise else x_new.cpu().numpy())
+
+    return pc_sampler

@@ -29,7 +29,7 @@ SIGNATURES = {
     "zedo_error_string": (ctypes.c_char_p, [_i]),
     "zedo_weights_create": (_i, [_vp, _sz, _i, _i, _i, _i, _i, _vp, ctypes.POINTER(_vp)]),
     "zedo_weights_destroy": (None, [_vp]),
-    "zedo_schedule_create": (_i, [_vp, _vp, _i, _f, _f, _i, _vp, ctypes.POINTER(_vp)]),
+    "zedo_schedule_create": (_i, [_vp, _vp, _i, _f, _f, _f, _i, _vp, ctypes.POINTER(_vp)]),
     "zedo_schedule_destroy": (None, [_vp]),
     "zedo_schedule_read": (_i, [_vp, _vp, _vp, _vp]),
     "zedo_workspace_bytes": (_sz, [_i]),
@@ -124,15 +124,15 @@ class Weights:
 class Schedule:
     """Per-step tables (time-bias rows, a_i, c_i) for one timestamp vector (zedo_schedule_create)."""
 
-    def __init__(self, weights, ts, beta_min=0.1, beta_max=20.0, n_sde=1000):
+    def __init__(self, weights, ts, beta_min=0.1, beta_max=20.0, n_sde=1000, label_scale=999.0):
         _need_gpu()
         ts = np.ascontiguousarray(np.asarray(ts, dtype=np.float32).reshape(-1))
         self.S = int(ts.size)
         self.ts = ts
         self.weights = weights  # keep alive
         self._h = ctypes.c_void_p()
-        _check(_lib.zedo_schedule_create(weights._h, ts.ctypes.data_as(_vp), self.S, beta_min, beta_max, n_sde,
-                                         _stream(), ctypes.byref(self._h)))
+        _check(_lib.zedo_schedule_create(weights._h, ts.ctypes.data_as(_vp), self.S, label_scale, beta_min, beta_max,
+                                         n_sde, _stream(), ctypes.byref(self._h)))
 
     def read(self):
         nl = 1 + 2 * self.weights.n_blocks
