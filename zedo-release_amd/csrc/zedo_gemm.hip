@@ -46,6 +46,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;   // K depth of one LDS tile (128-byte rows)
 
+// global -> LDS DMA of 64 x 16 bytes: source = wave-uniform 64-bit base + per-lane 32-bit byte offset, destination =
+// wave-uniform LDS byte address + lane*16.  Inline asm because hipcc materialises base + zext(offset) with a 64-bit
+// VALU add per instruction inside the K loop, and VALU issue time is matrix-pipe time here.  M0 (the LDS
+// destination) is compiler-reserved: it is saved and restored inside the statement.  hipcc does not count this load
+// in its vmcnt bookkeeping - every consumer below sits behind an explicit s_waitcnt vmcnt + barrier.
+__device__ __forceinline__ void dma16(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(sbase), "v"(voff), "s"(lds_byte_addr)
+                 : "memory");
+}
+
 __device__ __forceinline__ float silu_fast(float y) {
     // y * sigmoid(y) with hardware exp2 / rcp (each <= 1 ulp): |rel err| <= ~3e-7
     return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.44269504088896340736f));
@@ -96,19 +109,22 @@ __device__ long long *g_timeline = nullptr;   // ubench only: 8 x int64 per work
 #define TL_MARK(var)
 #endif
 
-// NODMA = 1 (ubench ablation only): skip the in-loop DMA to expose what staging costs.
-template <int BM, int BN, int WM, int WN, int EPI, int NODMA = 0>
+// NBUF = depth of the LDS tile ring (2 for the big tile, whose ring already fills the LDS; 3-4 for the small
+// tiles, whose iterations are shorter than the DMA latency).  NODMA = 1 (ubench ablation only).
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0>
 __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int TJ = TM / 32, TI = TN / 32;
     constexpr int IA = BN / 8 / NW, IB = BM / 8 / NW;   // DMA instructions (8 rows x 128 B each) per wave per tile
+    constexpr int IPW = IA + IB;                        // DMA instructions per wave per tile
     static_assert(TM % 32 == 0 && TN % 32 == 0 && IA >= 1 && IB >= 1 && (BN / 8) % NW == 0 && (BM / 8) % NW == 0, "tile");
+    static_assert(NBUF >= 2 && (NBUF - 1) * IPW <= 63, "ring depth vs the 6-bit vmcnt");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                 // [2][BN][32]  W tile, chunk-swizzled
-    float *Bs = smem + 2 * BN * BK;   // [2][BM][32]  X tile, chunk-swizzled
-    float *Ps = smem + 2 * (BM + BN) * BK;   // [3][BN]  bias | gamma | beta of this tile's channels (epilogue)
+    float *As = smem;                    // [NBUF][BN][32]  W tile, chunk-swizzled
+    float *Bs = smem + NBUF * BN * BK;   // [NBUF][BM][32]  X tile, chunk-swizzled
+    float *Ps = smem + NBUF * (BM + BN) * BK;   // [3][BN]  bias | gamma | beta of this tile's channels (epilogue)
 
     // XCD-aware, bijective block -> tile map: the hardware places block b on XCD b % 8; give every
     // XCD a contiguous range of tiles so that the column tiles of one row tile share one L2.
@@ -126,18 +142,23 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
 
     // ---- DMA addressing: instruction p of this wave fills LDS rows [(wid*I + p)*8, +8); lane -> (row, pos);
     //      LDS position `pos` of a row holds source chunk pos ^ (row & 7)
+    //      Addresses are kept as (wave-uniform 64-bit base, advanced with scalar adds) + (loop-invariant 32-bit
+    //      per-lane byte offset) so that the loads use the SGPR-base form and need no VALU address math.
     const int drow = lane >> 3, dpos = lane & 7;
-    const float *Wsrc = a.W + (size_t)(n0 + wid * IA * 8 + drow) * a.ldw + (dpos ^ drow) * 4;
-    const float *Xsrc = a.X + (size_t)(m0 + wid * IB * 8 + drow) * a.ldx + (dpos ^ drow) * 4;
+    const char *Wbase = reinterpret_cast<const char *>(a.W + (size_t)(n0 + wid * IA * 8) * a.ldw);
+    const char *Xbase = reinterpret_cast<const char *>(a.X + (size_t)(m0 + wid * IB * 8) * a.ldx);
+    const unsigned wlane = (unsigned)(drow * a.ldw + (dpos ^ drow) * 4) * 4u;
+    const unsigned xlane = (unsigned)(drow * a.ldx + (dpos ^ drow) * 4) * 4u;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)smem;   // LDS byte address of As
     auto dma = [&](int kt, int buf) {
+        const char *wk = Wbase + (size_t)kt * (BK * 4);
+        const char *xk = Xbase + (size_t)kt * (BK * 4);
 #pragma unroll
         for (int p = 0; p < IA; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Wsrc + (size_t)p * 8 * a.ldw + kt * BK),
-                                             (__attribute__((address_space(3))) void *)(As + (buf * BN + (wid * IA + p) * 8) * BK), 16, 0, 0);
+            dma16(wk + (size_t)p * 32 * a.ldw, wlane, lds0 + (unsigned)(((buf * BN + (wid * IA + p) * 8) * BK) * 4));
 #pragma unroll
         for (int p = 0; p < IB; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Xsrc + (size_t)p * 8 * a.ldx + kt * BK),
-                                             (__attribute__((address_space(3))) void *)(Bs + (buf * BM + (wid * IB + p) * 8) * BK), 16, 0, 0);
+            dma16(xk + (size_t)p * 32 * a.ldx, xlane, lds0 + (unsigned)(((NBUF * BN + buf * BM + (wid * IB + p) * 8) * BK) * 4));
     };
 
     // ---- fragment reads: k-chunk c = 2*kg + kh of row i lives at position c ^ (i & 7); tile bases are
@@ -171,10 +192,10 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     };
 
-    //   iteration kt (tile kt in buffer kt&1; F0 = fragments (kt, kg 0) already in registers):
+    //   iteration kt (tile kt in ring slot kt % NBUF; F0 = fragments (kt, kg 0) already in registers):
     //       F1 = read(kt,1); MFMA(F0);  F0 = read(kt,2); MFMA(F1);  F1 = read(kt,3); MFMA(F0)
-    //       barrier          <- all waves: reads of tile kt complete, DMA of tile kt+1 landed
-    //       DMA(tile kt+2 -> buffer kt&1);  F0 = read(kt+1, 0);  MFMA(F1)
+    //       vmcnt((NBUF-2)*IPW); barrier   <- all waves: reads of tile kt complete, DMA of tile kt+1 landed
+    //       DMA(tile kt+NBUF -> slot of tile kt);  F0 = read(kt+1, 0);  MFMA(F1)
     TL_MARK(tl0)
     // epilogue parameters -> LDS once (LDS reads are free next to MFMAs, VMEM loads are not)
     if (tid < BN / 4) {
@@ -185,29 +206,35 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
         }
     }
     const int KT = a.K / BK;
-    dma(0, 0);
-    dma(KT > 1 ? 1 : 0, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < NBUF; ++t) dma(min(t, KT - 1), t);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * IPW) : "memory");   // tile 0 landed
     __syncthreads();
     fread(fa0, fb0, 0, 0);
     TL_MARK(tl1)
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
+    // KT % NBUF == 0 (checked at launch): unrolling by NBUF makes the ring slot a compile-time constant, so
+    // every LDS offset folds into an instruction immediate (no VALU address math inside the loop).
+    for (int kt0 = 0; kt0 < KT; kt0 += NBUF) {
+#pragma unroll
+      for (int buf = 0; buf < NBUF; ++buf) {
+        const int kt = kt0 + buf;
+        const int nxt = (buf + 1 == NBUF) ? 0 : buf + 1;
         fread(fa1, fb1, buf, 1);
         mma(fa0, fb0);
         fread(fa0, fb0, buf, 2);
         mma(fa1, fb1);
         fread(fa1, fb1, buf, 3);
         mma(fa0, fb0);
-        // hipcc (ROCm 7.2) emits only lgkmcnt(0) before this barrier: it does not count the LDS-DMA issued
-        // one iteration ago, so wait for it explicitly (tile kt+1 must have landed in every wave's view).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // hipcc (ROCm 7.2) emits only lgkmcnt(0) before this barrier: it does not count the outstanding LDS-DMA,
+        // so wait explicitly until tile kt+1 has landed (the NBUF-2 younger tiles may stay in flight).
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
         __syncthreads();
         // Branch-free on purpose (one basic block, so these issue under the MFMAs below): past the last
         // tile the DMA refills a buffer nobody reads again and the fragment read fetches unused values.
-        if (!NODMA) dma(min(kt + 2, KT - 1), buf);
-        fread(fa0, fb0, buf ^ 1, 0);
+        if (!NODMA) dma(min(kt + NBUF, KT - 1), buf);
+        fread(fa0, fb0, nxt, 0);
         mma(fa1, fb1);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // drain the trailing (unused) DMA before any wave of the workgroup may exit
@@ -225,7 +252,7 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
         constexpr int CPRW = BN / 4;         // 16-byte chunks per stage row
         constexpr int RPI = 64 / CPRW;       // stage rows filled by one DMA instruction
         static_assert(CPRW <= 64 && 64 % CPRW == 0 && SR % (RPI * NW) == 0 && (SR * CPRW) % NT == 0, "stage shape");
-        static_assert((size_t)SR * BN <= (size_t)2 * (BM + BN) * BK, "stage must fit in the tile buffers");
+        static_assert((size_t)SR * BN <= (size_t)NBUF * (BM + BN) * BK, "stage must fit in the tile buffers");
         constexpr bool HAS_RES = (EPI == EPI_GN_SILU_RES || EPI == EPI_SDE);
         float *S = smem;
         float *obase = a.out + (size_t)m0 * a.ldo + n0;
@@ -303,11 +330,11 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NODMA = 0>
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0>
 static hipError_t launch_cfg(const LayerArgs &a, hipStream_t st) {
-    constexpr size_t lds = ((size_t)2 * (BM + BN) * BK + 3 * BN) * sizeof(float);
-    if (a.Mp <= 0 || a.Mp % BM || a.N % BN || a.K % BK) return hipErrorInvalidValue;
-    auto kern = layer_kernel<BM, BN, WM, WN, EPI, NODMA>;
+    constexpr size_t lds = ((size_t)NBUF * (BM + BN) * BK + 3 * BN) * sizeof(float);
+    if (a.Mp <= 0 || a.Mp % BM || a.N % BN || a.K % (BK * NBUF)) return hipErrorInvalidValue;
+    auto kern = layer_kernel<BM, BN, WM, WN, EPI, NBUF, NODMA>;
     static bool attr_done = false;  // per instantiation; benign race (idempotent call)
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -338,31 +365,45 @@ static LayerArgs rows_of(const LayerArgs &a, int row0, int rows) {
     return b;
 }
 
-// N == 1024 or 512 (hidden / embedding width): 256x256 tiles on the rows that fill whole rounds of the
-// chip (one 8-wave workgroup per CU), 64x128 tiles (launched first, so that they pack in front) on the rest.
+// Small-tile launches (remainder rows, pre_dense, schedule tables, small batches): their K iterations are
+// shorter than the DMA latency, so they run on a 3- or 4-deep LDS ring; the smallest batches get 32-row tiles
+// to spread over more CUs.
+template <int EPI>
+static hipError_t launch_small(const LayerArgs &a, hipStream_t st) {
+    if (a.Mp <= 2048 && a.Mp % 32 == 0) return launch_cfg<32, 128, 1, 4, EPI, 4>(a, st);
+    if (a.Mp <= 8192) return launch_cfg<64, 128, 2, 4, EPI, 4>(a, st);    // few workgroups: hide the DMA latency in the ring
+    return launch_cfg<64, 128, 2, 4, EPI, 2>(a, st);                      // many: three co-resident workgroups hide it
+}
+
+// N == 1024 or 512 (hidden / embedding width): 128x128 tiles (4 waves, two workgroups per CU so that one
+// workgroup's prologue / epilogue hides under the other's MFMAs) on the rows that fill whole rounds of the chip,
+// small tiles (launched first, so that they pack in front) on the rest.  With the DMA addressing free of VALU
+// work this beats 256x256 tiles (one workgroup per CU, nothing hides its epilogue): 735 / 754 us vs 746 / 771 us
+// per plain / residual layer at 49152 rows.
 template <int EPI>
 static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
-    const int per_round = num_cus() * 256 / (a.N / 256);          // rows covered by one full round of 256x256 tiles
+    // K <= 64 (pre_dense): almost no MFMA work per output, the layer is bound by writing the activation:
+    // many small co-resident workgroups overlap their stores, one big tile per CU cannot.
+    if (a.K <= 64) return launch_cfg<64, 128, 2, 4, EPI, 2>(a, st);
+    const int per_round = num_cus() * 2 * 128 / (a.N / 128);      // rows covered by one full round of 128x128 tiles, 2 per CU
     const int rows_big = (a.Mp / per_round) * per_round;
     const int rows_small = a.Mp - rows_big;                       // multiple of 256 (ROW_PAD)
     hipError_t e = hipSuccess;
-    // K <= 64 (pre_dense): almost no MFMA work per output, the layer is bound by writing the activation:
-    // many small co-resident workgroups overlap their stores, one big tile per CU cannot.
-    if (a.K <= 64) return launch_cfg<64, 128, 2, 4, EPI>(a, st);
-    if (rows_small > 0) e = launch_cfg<64, 128, 2, 4, EPI>(rows_of(a, rows_big, rows_small), st);
-    if (e == hipSuccess && rows_big > 0) e = launch_cfg<256, 256, 4, 2, EPI>(rows_of(a, 0, rows_big), st);
+    if (rows_small > 0) e = launch_small<EPI>(rows_of(a, rows_big, rows_small), st);
+    if (e == hipSuccess && rows_big > 0) e = launch_cfg<128, 128, 2, 2, EPI>(rows_of(a, 0, rows_big), st);
     return e;
 }
 
 hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
     if (a.N == XLD) {  // post_dense: 51 (padded to 64) output channels, one column tile
+        const bool small = a.Mp <= 8192 && a.Mp % 32 == 0;
         switch (epilogue) {
-            case EPI_SDE: return launch_cfg<128, 64, 4, 1, EPI_SDE>(a, st);
-            case EPI_BIAS: return launch_cfg<128, 64, 4, 1, EPI_BIAS>(a, st);
+            case EPI_SDE: return small ? launch_cfg<32, 64, 1, 2, EPI_SDE, 4>(a, st) : launch_cfg<128, 64, 4, 1, EPI_SDE, 4>(a, st);
+            case EPI_BIAS: return small ? launch_cfg<32, 64, 1, 2, EPI_BIAS, 4>(a, st) : launch_cfg<128, 64, 4, 1, EPI_BIAS, 4>(a, st);
         }
         return hipErrorInvalidValue;
     }
-    if (a.N % 256) return hipErrorInvalidValue;
+    if (a.N % 128) return hipErrorInvalidValue;
     switch (epilogue) {
         case EPI_GN_SILU: return launch_wide<EPI_GN_SILU>(a, st);
         case EPI_GN_SILU_RES: return launch_wide<EPI_GN_SILU_RES>(a, st);
@@ -374,17 +415,20 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
 
 #ifdef ZEDO_UBENCH
 // ---- variant table for tools/ubench/ubench_gemm.hip ----
-constexpr int UBENCH_NVAR = 8;
+constexpr int UBENCH_NVAR = 11;
 static const char *variant_name(int v) {
     switch (v) {
-        case 0: return "product launch_layer (256x256 + 64x128 remainder)";
+        case 0: return "product launch_layer (128x128 x2/CU + 64x128 remainder)";
         case 1: return "128x128 4 waves (2x2)";
         case 2: return "256x128 8 waves (4x2)";
         case 3: return "256x256 8 waves (4x2)";
         case 4: return "256x256 8 waves (2x4)";
-        case 5: return "64x128 8 waves (2x4)";
+        case 5: return "64x128 8 waves (2x4), 4-deep ring";
         case 6: return "256x256 (4x2), no in-loop DMA [ablation]";
         case 7: return "product, GN_SILU_RES epilogue";
+        case 8: return "128x128 4 waves (2x2), GN_SILU_RES";
+        case 9: return "128x256 4 waves (1x4... 2x2 of 64x128)";
+        case 10: return "256x128 4 waves (2x2 of 128x64)";
     }
     return "?";
 }
@@ -395,9 +439,12 @@ static hipError_t launch_variant(const LayerArgs &a, int v, hipStream_t st) {
         case 2: return launch_cfg<256, 128, 4, 2, EPI_GN_SILU>(a, st);
         case 3: return launch_cfg<256, 256, 4, 2, EPI_GN_SILU>(a, st);
         case 4: return launch_cfg<256, 256, 2, 4, EPI_GN_SILU>(a, st);
-        case 5: return launch_cfg<64, 128, 2, 4, EPI_GN_SILU>(a, st);
-        case 6: return launch_cfg<256, 256, 4, 2, EPI_GN_SILU, 1>(a, st);
+        case 5: return launch_cfg<64, 128, 2, 4, EPI_GN_SILU, 4>(a, st);
+        case 6: return launch_cfg<256, 256, 4, 2, EPI_GN_SILU, 2, 1>(a, st);
         case 7: return launch_layer(a, EPI_GN_SILU_RES, st);
+        case 8: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES>(a, st);
+        case 9: return launch_cfg<128, 256, 2, 2, EPI_GN_SILU>(a, st);
+        case 10: return launch_cfg<256, 128, 2, 2, EPI_GN_SILU>(a, st);
     }
     return hipErrorInvalidValue;
 }

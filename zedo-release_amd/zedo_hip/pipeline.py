@@ -10,6 +10,8 @@ batched as rows (h, n) and every stage running in libzedo_hip.so.
 Rows may be a contiguous shard of the H*N global rows (one shard per GPU); the only exchange is the final
 MIN over ranks, done by the caller (run/opt_main.py, bench.py) with torch.distributed.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -96,7 +98,8 @@ def reduce_min_over_ranks(best, idx):
     """The one exchange step of the sharded path: MIN over ranks of the per-pose error (RCCL all-reduce),
     then the lowest hypothesis index among the ranks that hold that minimum."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or \
+            (dist.get_world_size() == 1 and os.environ.get("ZEDO_BENCH_FORCE_DIST") != "1"):
         return best, idx
     g = best.clone()
     dist.all_reduce(g, op=dist.ReduceOp.MIN)
