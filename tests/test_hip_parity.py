@@ -274,3 +274,61 @@ def test_rows_are_independent_at_full_size(zh, W):
     x2 = x + g1
     g2 = zh.reproj_grad(x2, geom, T, False)
     assert g2.abs().max().item() < 1e-5 * max(1.0, x2.abs().max().item() + T.abs().max().item())
+
+
+# ---------------------------------------------------------------- argument validation, chunking
+
+def test_bad_arguments_are_rejected(zh, W):
+    import ctypes
+    import zedo_oracle as O
+    lib = zh._lib
+    s = zh.Schedule(W, O.oil_timestamps(10))
+    x = torch.zeros(4, 17, 3, device="cuda")
+    ws = zh.workspace(4)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    # step out of range, B = 0, NULL pointers, workspace too small -> negative ZEDO_E_* codes, nothing launched
+    assert lib.zedo_sde_step(W._h, s._h, 10, P(x), 4, P(ws), ws.numel(), None) == -1
+    assert lib.zedo_sde_step(W._h, s._h, 0, P(x), 0, P(ws), ws.numel(), None) == -1
+    assert lib.zedo_sde_step(W._h, s._h, 0, None, 4, P(ws), ws.numel(), None) == -1
+    assert lib.zedo_sde_step(W._h, s._h, 0, P(x), 4, P(ws), 16, None) == -3
+    assert lib.zedo_oil_run(W._h, s._h, P(x), None, None, 0, 5, 1, 4, 4, 0, P(ws), ws.numel(), None) == -1
+    assert lib.zedo_workspace_bytes(0) == 0
+    with pytest.raises(zh.ZedoError):
+        zh.Schedule(W, np.zeros(0, np.float32))
+    with pytest.raises(zh.ZedoError):       # wrong parameter count
+        bad = dict(W_bad=None)
+        zh.Weights({k: np.zeros(3, np.float32) for k in zh.param_names()})
+    with pytest.raises(zh.ZedoError):       # host tensor where a device tensor is required
+        zh.reproj_prepare(torch.zeros(2, 17, 2), torch.zeros(2, 3, 3))
+    assert b"argument" in lib.zedo_error_string(-1)
+
+
+def test_row_chunking_is_bitwise_neutral(tmp_path):
+    """ZEDO_CHUNK_ROWS bounds the workspace for very large batches (BASELINE config 5: 5 M rows); the chunk
+    loop must give exactly the rows of the unchunked run.  Separate processes: the cap is read once."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.join(%r, "zedo-release_amd")); sys.path.insert(0, os.path.join(%r, "oracle"))
+import zedo_hip as zh, zedo_oracle as O
+from lib.dataset import synthetic as syn
+H, N, S = 5, 301, 7
+d = syn.make_poses(N, seed=4, conf_mode="uniform")
+rng = np.random.default_rng(1)
+x0 = (0.25 * rng.standard_normal((H * N, 17, 3))).astype(np.float32)
+T0 = np.tile(d["db_3d"][:, 0, :], (H, 1)).astype(np.float32)
+dev = lambda a: torch.tensor(a, device="cuda")
+W = zh.Weights(syn.make_weights(0)); s = zh.Schedule(W, O.oil_timestamps(S))
+geom = zh.reproj_prepare(dev(d["db_2d"][:, :, :2].copy()), dev(d["camera_param"]), dev(d["db_2d"][:, :, 2].copy()))
+x, T = dev(x0), dev(T0)
+zh.oil_run(W, s, x, geom, T, 0, S, 2)
+np.savez(sys.argv[1], x=x.cpu().numpy(), T=T.cpu().numpy(), ws=zh.workspace_bytes(H * N))
+''' % (root, root)
+    outs = []
+    for tag, env in (("full", {}), ("chunk", {"ZEDO_CHUNK_ROWS": "512"})):
+        out = str(tmp_path / f"{tag}.npz")
+        subprocess.run([sys.executable, "-c", code, out], check=True, env={**os.environ, **env})
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0]["x"], outs[1]["x"]) and np.array_equal(outs[0]["T"], outs[1]["T"])
+    assert int(outs[1]["ws"]) == 512 * (64 + 2048) * 4 < int(outs[0]["ws"])

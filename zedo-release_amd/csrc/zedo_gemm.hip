@@ -197,6 +197,8 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
     //       vmcnt((NBUF-2)*IPW); barrier   <- all waves: reads of tile kt complete, DMA of tile kt+1 landed
     //       DMA(tile kt+NBUF -> slot of tile kt);  F0 = read(kt+1, 0);  MFMA(F1)
     TL_MARK(tl0)
+    // (s_setprio around prologue / epilogue was measured: no effect - their starvation behind the partner's
+    //  pending MFMAs is structural, not a priority matter.)
     // epilogue parameters -> LDS once (LDS reads are free next to MFMAs, VMEM loads are not)
     if (tid < BN / 4) {
         *reinterpret_cast<f32x4 *>(Ps + tid * 4) = *reinterpret_cast<const f32x4 *>(a.bias + n0 + tid * 4);
