@@ -44,7 +44,6 @@ namespace zedo {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;   // K depth of one LDS tile (128-byte rows)
 
 // global -> LDS DMA of 64 x 16 bytes: source = wave-uniform 64-bit base + per-lane 32-bit byte offset, destination =
 // wave-uniform LDS byte address + lane*16.  Inline asm because hipcc materialises base + zext(offset) with a 64-bit
@@ -111,14 +110,20 @@ __device__ long long *g_timeline = nullptr;   // ubench only: 8 x int64 per work
 
 // NBUF = depth of the LDS tile ring (2 for the big tile, whose ring already fills the LDS; 3-4 for the small
 // tiles, whose iterations are shorter than the DMA latency).  NODMA = 1 (ubench ablation only).
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0>
+// BK = K depth of one LDS tile: 32 (128-byte rows) or 16 (64-byte rows: half the LDS, so that three 128x128
+// workgroups fit on a CU).
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32>
 __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
     constexpr int NW = WM * WN;
+    constexpr int CPR = BK / 4;                         // 16-byte chunks per tile row (8 or 4)
+    constexpr int RPD = 64 / CPR;                       // tile rows moved by one DMA instruction (8 or 16)
+    constexpr int KG = BK / 8;                          // fragment groups (8 k each) per tile
+    static_assert(BK == 32 || BK == 16, "BK");
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int TJ = TM / 32, TI = TN / 32;
-    constexpr int IA = BN / 8 / NW, IB = BM / 8 / NW;   // DMA instructions (8 rows x 128 B each) per wave per tile
+    constexpr int IA = BN / RPD / NW, IB = BM / RPD / NW;   // DMA instructions (1 KB each) per wave per tile
     constexpr int IPW = IA + IB;                        // DMA instructions per wave per tile
-    static_assert(TM % 32 == 0 && TN % 32 == 0 && IA >= 1 && IB >= 1 && (BN / 8) % NW == 0 && (BM / 8) % NW == 0, "tile");
+    static_assert(TM % 32 == 0 && TN % 32 == 0 && IA >= 1 && IB >= 1 && (BN / RPD) % NW == 0 && (BM / RPD) % NW == 0, "tile");
     static_assert(NBUF >= 2 && (NBUF - 1) * IPW <= 63, "ring depth vs the 6-bit vmcnt");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -140,32 +145,35 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
     const int wm = wid / WN, wn = wid % WN;
     const int li = lane & 31, kh = lane >> 5;
 
-    // ---- DMA addressing: instruction p of this wave fills LDS rows [(wid*I + p)*8, +8); lane -> (row, pos);
-    //      LDS position `pos` of a row holds source chunk pos ^ (row & 7)
+    // ---- DMA addressing: instruction p of this wave fills LDS rows [(wid*I + p)*RPD, +RPD); lane -> (row, pos);
+    //      LDS position `pos` of a row holds source chunk pos ^ swz(row), swz(r) = r & 7 (128-byte rows) or
+    //      (r >> 2) & 3 (64-byte rows): both make a ds_read_b128 of 16 consecutive rows hit 16 distinct slots
     //      Addresses are kept as (wave-uniform 64-bit base, advanced with scalar adds) + (loop-invariant 32-bit
     //      per-lane byte offset) so that the loads use the SGPR-base form and need no VALU address math.
-    const int drow = lane >> 3, dpos = lane & 7;
-    const char *Wbase = reinterpret_cast<const char *>(a.W + (size_t)(n0 + wid * IA * 8) * a.ldw);
-    const char *Xbase = reinterpret_cast<const char *>(a.X + (size_t)(m0 + wid * IB * 8) * a.ldx);
-    const unsigned wlane = (unsigned)(drow * a.ldw + (dpos ^ drow) * 4) * 4u;
-    const unsigned xlane = (unsigned)(drow * a.ldx + (dpos ^ drow) * 4) * 4u;
+    const int drow = lane / CPR, dpos = lane % CPR;
+    const int dswz = (BK == 32) ? (drow & 7) : ((drow >> 2) & 3);
+    const char *Wbase = reinterpret_cast<const char *>(a.W + (size_t)(n0 + wid * IA * RPD) * a.ldw);
+    const char *Xbase = reinterpret_cast<const char *>(a.X + (size_t)(m0 + wid * IB * RPD) * a.ldx);
+    const unsigned wlane = (unsigned)(drow * a.ldw + (dpos ^ dswz) * 4) * 4u;
+    const unsigned xlane = (unsigned)(drow * a.ldx + (dpos ^ dswz) * 4) * 4u;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)smem;   // LDS byte address of As
     auto dma = [&](int kt, int buf) {
         const char *wk = Wbase + (size_t)kt * (BK * 4);
         const char *xk = Xbase + (size_t)kt * (BK * 4);
 #pragma unroll
         for (int p = 0; p < IA; ++p)
-            dma16(wk + (size_t)p * 32 * a.ldw, wlane, lds0 + (unsigned)(((buf * BN + (wid * IA + p) * 8) * BK) * 4));
+            dma16(wk + (size_t)p * (RPD * 4) * a.ldw, wlane, lds0 + (unsigned)(((buf * BN + (wid * IA + p) * RPD) * BK) * 4));
 #pragma unroll
         for (int p = 0; p < IB; ++p)
-            dma16(xk + (size_t)p * 32 * a.ldx, xlane, lds0 + (unsigned)(((NBUF * BN + buf * BM + (wid * IB + p) * 8) * BK) * 4));
+            dma16(xk + (size_t)p * (RPD * 4) * a.ldx, xlane, lds0 + (unsigned)(((NBUF * BN + buf * BM + (wid * IB + p) * RPD) * BK) * 4));
     };
 
-    // ---- fragment reads: k-chunk c = 2*kg + kh of row i lives at position c ^ (i & 7); tile bases are
-    //      multiples of 8 rows, so i & 7 == li & 7 and the four offsets are loop invariant
-    int foff[4];
+    // ---- fragment reads: k-chunk c = 2*kg + kh of row i lives at position c ^ swz(i); tile bases are
+    //      multiples of 32 rows, so swz(i) == swz(li) and the offsets are loop invariant
+    const int fswz = (BK == 32) ? (li & 7) : ((li >> 2) & 3);
+    int foff[KG];
 #pragma unroll
-    for (int kg = 0; kg < 4; ++kg) foff[kg] = ((2 * kg + kh) ^ (li & 7)) * 4;
+    for (int kg = 0; kg < KG; ++kg) foff[kg] = ((2 * kg + kh) ^ fswz) * 4;
     const float *Ab0 = As + (wn * TN + li) * BK;
     const float *Bb0 = Bs + (wm * TM + li) * BK;
     f32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
@@ -223,10 +231,12 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
         const int nxt = (buf + 1 == NBUF) ? 0 : buf + 1;
         fread(fa1, fb1, buf, 1);
         mma(fa0, fb0);
-        fread(fa0, fb0, buf, 2);
-        mma(fa1, fb1);
-        fread(fa1, fb1, buf, 3);
-        mma(fa0, fb0);
+        if constexpr (KG == 4) {
+            fread(fa0, fb0, buf, 2);
+            mma(fa1, fb1);
+            fread(fa1, fb1, buf, 3);
+            mma(fa0, fb0);
+        }
         // hipcc (ROCm 7.2) emits only lgkmcnt(0) before this barrier: it does not count the outstanding LDS-DMA,
         // so wait explicitly until tile kt+1 has landed (the NBUF-2 younger tiles may stay in flight).
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
@@ -332,11 +342,11 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0>
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32>
 static hipError_t launch_cfg(const LayerArgs &a, hipStream_t st) {
     constexpr size_t lds = ((size_t)NBUF * (BM + BN) * BK + 3 * BN) * sizeof(float);
     if (a.Mp <= 0 || a.Mp % BM || a.N % BN || a.K % (BK * NBUF)) return hipErrorInvalidValue;
-    auto kern = layer_kernel<BM, BN, WM, WN, EPI, NBUF, NODMA>;
+    auto kern = layer_kernel<BM, BN, WM, WN, EPI, NBUF, NODMA, BK>;
     static bool attr_done = false;  // per instantiation; benign race (idempotent call)
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -417,7 +427,7 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
 
 #ifdef ZEDO_UBENCH
 // ---- variant table for tools/ubench/ubench_gemm.hip ----
-constexpr int UBENCH_NVAR = 11;
+constexpr int UBENCH_NVAR = 17;
 static const char *variant_name(int v) {
     switch (v) {
         case 0: return "product launch_layer (128x128 x2/CU + 64x128 remainder)";
@@ -431,6 +441,12 @@ static const char *variant_name(int v) {
         case 8: return "128x128 4 waves (2x2), GN_SILU_RES";
         case 9: return "128x256 4 waves (1x4... 2x2 of 64x128)";
         case 10: return "256x128 4 waves (2x2 of 128x64)";
+        case 11: return "128x128 4 waves, BK16 ring of 2 (3 WG/CU)";
+        case 12: return "128x128 4 waves, BK16 ring of 4 (2 WG/CU)";
+        case 13: return "256x128 4 waves (128x64 each), BK16 ring 2";
+        case 14: return "128x128 4 waves, BK16 ring 2, GN_SILU_RES";
+        case 15: return "256x128 4 waves, BK16 ring 2, GN_SILU_RES";
+        case 16: return "256x128 4 waves (128x64 each), BK16 ring 4";
     }
     return "?";
 }
@@ -447,6 +463,12 @@ static hipError_t launch_variant(const LayerArgs &a, int v, hipStream_t st) {
         case 8: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES>(a, st);
         case 9: return launch_cfg<128, 256, 2, 2, EPI_GN_SILU>(a, st);
         case 10: return launch_cfg<256, 128, 2, 2, EPI_GN_SILU>(a, st);
+        case 11: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 16>(a, st);
+        case 12: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 4, 0, 16>(a, st);
+        case 13: return launch_cfg<256, 128, 2, 2, EPI_GN_SILU, 2, 0, 16>(a, st);
+        case 14: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 16>(a, st);
+        case 15: return launch_cfg<256, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 16>(a, st);
+        case 16: return launch_cfg<256, 128, 2, 2, EPI_GN_SILU, 4, 0, 16>(a, st);
     }
     return hipErrorInvalidValue;
 }
