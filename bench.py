@@ -154,7 +154,7 @@ def main():
             tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC pass, collected separately
             if os.path.exists(tp):
                 traffic = json.load(open(tp)).get("hidden_dense_bytes_per_launch")
-            roof = dict(bound="mfma", kernel="zedo::layer_kernel<128,128,2,2,{GN_SILU|GN_SILU_RES}> + its small-tile remainder launch: "
+            roof = dict(bound="mfma", kernel="zedo::layer_pair_kernel<{GN_SILU|GN_SILU_RES}> (128x128 tiles, 2 workgroups per CU, + 32x128 remainder tiles in the same launch): "
                                              "one 1024x1024 dense layer + GroupNorm + SiLU [+ residual] over all rows",
                         achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,

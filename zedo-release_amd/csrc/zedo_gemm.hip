@@ -113,7 +113,7 @@ __device__ long long *g_timeline = nullptr;   // ubench only: 8 x int64 per work
 // BK = K depth of one LDS tile: 32 (128-byte rows) or 16 (64-byte rows: half the LDS, so that three 128x128
 // workgroups fit on a CU).
 template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32>
-__global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
+__device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, const int nwg) {
     constexpr int NW = WM * WN;
     constexpr int CPR = BK / 4;                         // 16-byte chunks per tile row (8 or 4)
     constexpr int RPD = 64 / CPR;                       // tile rows moved by one DMA instruction (8 or 16)
@@ -133,7 +133,6 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
 
     // XCD-aware, bijective block -> tile map: the hardware places block b on XCD b % 8; give every
     // XCD a contiguous range of tiles so that the column tiles of one row tile share one L2.
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int ncol = a.N / BN;
@@ -343,6 +342,37 @@ __global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32>
+__global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
+    layer_body<BM, BN, WM, WN, EPI, NBUF, NODMA, BK>(a, blockIdx.x, gridDim.x);
+}
+
+// One launch, two tile shapes: workgroups [0, nbig) run 128x128 tiles on the rows that fill whole rounds of the
+// chip, workgroups [nbig, grid) run 32x128 tiles on the remainder rows.  Workgroups are dispatched in order, so the
+// small tiles start as CUs run out of big tiles and fill the tail of the launch instead of costing a separate,
+// latency-bound launch (40 us -> ~15 us per layer at 50 750 rows).  Both shapes use 256 threads.
+template <int EPI>
+__global__ __launch_bounds__(256) void layer_pair_kernel(LayerArgs big, LayerArgs small, int nbig) {
+    if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 2, EPI, 2, 0, 32>(big, blockIdx.x, nbig);
+    else layer_body<32, 128, 1, 4, EPI, 2, 0, 32>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+}
+
+template <int EPI>
+static hipError_t launch_pair(const LayerArgs &big, const LayerArgs &small, hipStream_t st) {
+    constexpr size_t lds = ((size_t)2 * (128 + 128) * 32 + 3 * 128) * sizeof(float);   // the big shape's need covers the small one's
+    if (big.Mp % 128 || small.Mp % 32 || big.N % 128 || big.K % 64) return hipErrorInvalidValue;
+    auto kern = layer_pair_kernel<EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int nbig = (big.Mp / 128) * (big.N / 128), nsmall = (small.Mp / 32) * (small.N / 128);
+    hipLaunchKernelGGL(kern, dim3(nbig + nsmall), dim3(256), lds, st, big, small, nbig);
+    return hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32>
 static hipError_t launch_cfg(const LayerArgs &a, hipStream_t st) {
     constexpr size_t lds = ((size_t)NBUF * (BM + BN) * BK + 3 * BN) * sizeof(float);
     if (a.Mp <= 0 || a.Mp % BM || a.N % BN || a.K % (BK * NBUF)) return hipErrorInvalidValue;
@@ -396,10 +426,14 @@ template <int EPI>
 static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
     // K <= 64 (pre_dense): almost no MFMA work per output, the layer is bound by writing the activation:
     // many small co-resident workgroups overlap their stores, one big tile per CU cannot.
+    // (measured at 50 750 rows: 64x128 82 us; 32x128 92 us; 128x128 91 us; 64x256 108 us)
     if (a.K <= 64) return launch_cfg<64, 128, 2, 4, EPI, 2>(a, st);
     const int per_round = num_cus() * 2 * 128 / (a.N / 128);      // rows covered by one full round of 128x128 tiles, 2 per CU
     const int rows_big = (a.Mp / per_round) * per_round;
     const int rows_small = a.Mp - rows_big;                       // multiple of 256 (ROW_PAD)
+    static const bool split_launch = getenv("ZEDO_SPLIT_REMAINDER") != nullptr;   // A/B knob: remainder as its own launch
+    if (rows_small > 0 && rows_big > 0 && !split_launch)
+        return launch_pair<EPI>(rows_of(a, 0, rows_big), rows_of(a, rows_big, rows_small), st);
     hipError_t e = hipSuccess;
     if (rows_small > 0) e = launch_small<EPI>(rows_of(a, rows_big, rows_small), st);
     if (e == hipSuccess && rows_big > 0) e = launch_cfg<128, 128, 2, 2, EPI>(rows_of(a, 0, rows_big), st);
@@ -408,10 +442,12 @@ static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
 
 hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
     if (a.N == XLD) {  // post_dense: 51 (padded to 64) output channels, one column tile
+        // bandwidth bound (reads the 4 KB activation row once): 64-row tiles, two workgroups per CU, 4-deep ring
+        // (measured 70.6 us vs 75.7 us for 128-row tiles and 88 us for 32-row tiles at 50 750 rows)
         const bool small = a.Mp <= 8192 && a.Mp % 32 == 0;
         switch (epilogue) {
-            case EPI_SDE: return small ? launch_cfg<32, 64, 1, 2, EPI_SDE, 4>(a, st) : launch_cfg<128, 64, 4, 1, EPI_SDE, 4>(a, st);
-            case EPI_BIAS: return small ? launch_cfg<32, 64, 1, 2, EPI_BIAS, 4>(a, st) : launch_cfg<128, 64, 4, 1, EPI_BIAS, 4>(a, st);
+            case EPI_SDE: return small ? launch_cfg<32, 64, 1, 2, EPI_SDE, 4>(a, st) : launch_cfg<64, 64, 2, 2, EPI_SDE, 4>(a, st);
+            case EPI_BIAS: return small ? launch_cfg<32, 64, 1, 2, EPI_BIAS, 4>(a, st) : launch_cfg<64, 64, 2, 2, EPI_BIAS, 4>(a, st);
         }
         return hipErrorInvalidValue;
     }
@@ -430,7 +466,7 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
 constexpr int UBENCH_NVAR = 17;
 static const char *variant_name(int v) {
     switch (v) {
-        case 0: return "product launch_layer (128x128 x2/CU + 64x128 remainder)";
+        case 0: return "product launch_layer (128x128 x2/CU + 32x128 remainder, one launch)";
         case 1: return "128x128 4 waves (2x2)";
         case 2: return "256x128 8 waves (4x2)";
         case 3: return "256x256 8 waves (4x2)";
