@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DZEDO_UBENCH tools/ubench/ubench_gemm.hip -o tools/ubench/ubench_gemm
 #include "../../zedo-release_amd/csrc/zedo_gemm.hip"
 #include <cstdio>
+#include <chrono>
 #include <vector>
 #include <random>
 
@@ -59,7 +60,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dg, hg.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dbe, hbe.data(), N * 4, hipMemcpyHostToDevice));
     LayerArgs a{}; a.X = dx; a.ldx = K; a.W = dw; a.ldw = K; a.bias = db; a.gamma = dg; a.beta = dbe; a.out = dy; a.ldo = N; a.K = K; a.N = N; a.Mp = M;
-    if (argc > 2) {   // timeline dump: ubench_gemm M variant out.bin
+    if (argc > 2 && atoi(argv[2]) >= 0) {   // timeline dump: ubench_gemm M variant out.bin
         const int var = atoi(argv[2]);
         long long *dtl; const size_t NWG = (size_t)(M / 64) * 8; CK(hipMalloc(&dtl, NWG * 64)); CK(hipMemset(dtl, 0, NWG * 64));
         for (int r = 0; r < 300; ++r) launch_variant(a, var, 0);
@@ -71,6 +72,23 @@ int main(int argc, char **argv) {
         FILE *f = fopen(argc > 3 ? argv[3] : "gpurun_out/wg_timeline.bin", "wb");
         fwrite(tl.data(), 8, tl.size(), f); fclose(f);
         printf("timeline of variant %d written\n", var);
+        return 0;
+    }
+    if (argc > 2 && atoi(argv[2]) == -1) {   // overlap test: hidden layer on stream 1, pre_dense-like layer on stream 2
+        hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+        float *dx2, *dy2; CK(hipMalloc(&dx2, (size_t)M * 64 * 4)); CK(hipMalloc(&dy2, (size_t)M * N * 4));
+        CK(hipMemcpy(dx2, hx.data(), (size_t)M * 64 * 4, hipMemcpyHostToDevice));
+        LayerArgs b = a; b.X = dx2; b.ldx = 64; b.ldw = K; b.K = 64; b.out = dy2;
+        auto timeit = [&](int mode) -> float {
+            for (int r = 0; r < 200; ++r) { if (mode & 1) launch_layer(a, EPI_GN_SILU, s1); if (mode & 2) launch_layer(b, EPI_GN_SILU, s2); }
+            hipDeviceSynchronize();
+            auto t0 = std::chrono::high_resolution_clock::now();
+            for (int r = 0; r < 100; ++r) { if (mode & 1) launch_layer(a, EPI_GN_SILU, s1); if (mode & 2) launch_layer(b, EPI_GN_SILU, s2); }
+            hipDeviceSynchronize();
+            return std::chrono::duration<float, std::micro>(std::chrono::high_resolution_clock::now() - t0).count() / 100;
+        };
+        const float th = timeit(1), tl = timeit(2), tb = timeit(3);
+        printf("rows %d: hidden alone %.1f us, light alone %.1f us, both on two streams %.1f us (sum %.1f)\n", M, th, tl, tb, th + tl);
         return 0;
     }
     // CPU reference (double) for GN+SiLU on a sample of rows spread over the whole batch
