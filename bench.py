@@ -148,7 +148,10 @@ def main():
         hid = prof["hidden_dense"]
         roof = None
         if hid["avg_ms"]:
-            flop_launch = 2.0 * rows * 1024 * 1024
+            # zedo_oil_run walks the rows in chunks of at most ZEDO_CHUNK_ROWS (default 2^20) per launch
+            cap = int(os.environ.get("ZEDO_CHUNK_ROWS", 1 << 20))
+            rows_launch = rows / -(-rows // cap)
+            flop_launch = 2.0 * rows_launch * 1024 * 1024
             ach = flop_launch / (hid["avg_ms"] * 1e-3) / 1e12
             traffic = None
             tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC pass, collected separately
