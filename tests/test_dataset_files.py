@@ -1,0 +1,60 @@
+"""Dataset readers against files: tests/golden/assets holds small synthetic files in the
+formats of the reference's assets (h36m_test.pkl, h36m_sh_dt_ft.pkl, pw3d_test.npz); tests/golden/datasets.npz
+holds what the REFERENCE's readers (lib/dataset/h36m.py:206-263, lib/dataset/pw3d.py:177-227) returned for them
+(tools/gen_golden.py::gen_datasets).  Arrays must match bit for bit, dtypes included."""
+import os
+
+import numpy as np
+import pytest
+
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assets")
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("tag,kw", [("gt", dict(gt2d=True)), ("dt", dict(gt2d=False)),
+                                    ("gt_s3", dict(gt2d=True, sample_interval=3)),
+                                    ("dt_rel", dict(gt2d=False, abs_coord=False))])
+def test_h36m_reader_matches_the_reference(golden, tag, kw):
+    from lib.dataset.h36m import H36MDataset3D
+    g = golden("datasets")
+    kw = dict(dict(abs_coord=True), **kw)
+    ds = H36MDataset3D(os.path.join(ASSETS, "h36m"), "test", flip=False, **kw)
+    for name in ("db_2d", "db_3d", "camera_param"):
+        assert same(getattr(ds, name), g[f"h36m_{tag}_{name}"]), (tag, name, getattr(ds, name).dtype)
+    assert [d["action"] for d in ds.gt_dataset] == list(g[f"h36m_{tag}_actions"])
+    assert len(ds) == int(g[f"h36m_{tag}_len"]) == ds.real_data_len
+    assert len(ds.image_name) == len(ds.db_2d) and ds.image_name[0].endswith(".jpg")
+
+
+@pytest.mark.parametrize("tag,kw", [("abs", dict(abs_coord=True)), ("abs_s4", dict(abs_coord=True, sample_interval=4)),
+                                    ("rel", dict(abs_coord=False))])
+def test_pw3d_reader_matches_the_reference(golden, tag, kw):
+    from lib.dataset.pw3d import PW3D
+    g = golden("datasets")
+    ds = PW3D(os.path.join(ASSETS, "3dpw"), "test", gt2d=True, flip=False, **kw)
+    for name in ("db_2d", "db_3d", "camera_param", "w", "h"):
+        assert same(getattr(ds, name), g[f"pw3d_{tag}_{name}"]), (tag, name, getattr(ds, name).dtype)
+    assert [str(s) for s in ds.image_name] == [str(s) for s in g[f"pw3d_{tag}_image_name"]]
+
+
+def test_pw3d_joint_reorder_is_the_reference_permutation():
+    from lib.dataset.pw3d import PW3D, ORDER
+    ds = object.__new__(PW3D)
+    ds.order = ORDER
+    x = np.arange(17 * 3, dtype=np.float32).reshape(17, 3)
+    y = ds.order_change(x)
+    for i in range(17):
+        assert np.array_equal(y[ORDER[i]], x[i])
+
+
+def test_missing_files_fail_loudly(tmp_path):
+    from lib.dataset.h36m import H36MDataset3D
+    from lib.dataset.pw3d import PW3D
+    with pytest.raises(FileNotFoundError):
+        H36MDataset3D(str(tmp_path), "test")
+    with pytest.raises(FileNotFoundError):
+        PW3D(str(tmp_path), "test")

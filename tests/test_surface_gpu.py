@@ -157,3 +157,49 @@ def test_run_opt_main_and_inference_synthetic(tmp_path):
     res, errs = inf.main(b)
     assert res.shape == (30, 2, 17, 3) and np.load(out).shape == (30, 2, 17, 3) and np.isfinite(res).all()
     assert errs is not None and all(np.isfinite(e) for e in errs)
+
+
+@pytest.mark.parametrize("tag,flags", [("gt", ["--gt"]), ("dt", [])])
+def test_opt_main_from_files_matches_reference(tmp_path, golden, weights0, tag, flags, monkeypatch):
+    """the driver fed from FILES in the reference's formats - data/h36m/h36m_test.pkl
+    (+ h36m_sh_dt_ft.pkl detections), clusters/h36m_cluster{H}.npy, a DataParallel-style checkpoint .pth -
+    against the reference's readers + loop + action-wise eval_multi on the same files
+    (tools/gen_golden.py::gen_driver_files; N=20, H=2, S=60).  Bar: 0.05 mm (BASELINE.json north_star)."""
+    import shutil
+    import run.opt_main as om
+    from lib.algorithms.advanced.model import ScoreModelFC_Adv
+    from lib.algorithms.ema import ExponentialMovingAverage
+    from lib.dataset import synthetic as syn
+    from run._driver import load_config
+    g = golden("driver_files")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shutil.copytree(os.path.join(root, "tests", "golden", "assets", "h36m"), tmp_path / "data" / "h36m")
+    os.makedirs(tmp_path / "clusters")
+    np.save(tmp_path / "clusters" / "h36m_cluster2.npy", g["clusters"])
+    cfg_file = tmp_path / "cfg_h36m_small.py"
+    cfg_file.write_text(
+        "import importlib.util\n"
+        f"_s = importlib.util.spec_from_file_location('base_cfg', r'{cfg_path('h36m')}')\n"
+        "_m = importlib.util.module_from_spec(_s); _s.loader.exec_module(_m)\n"
+        "def get_config():\n"
+        "    c = _m.get_config()\n"
+        "    c.ZeDO.sample = None\n"
+        "    c.ZeDO.batch = 20\n"
+        "    return c\n")
+    # checkpoint in the layout the reference's training script writes (DataParallel 'module.' prefix, ema, step)
+    model = ScoreModelFC_Adv(load_config(str(cfg_file)), n_joints=17, joint_dim=3, hidden_dim=1024, embed_dim=512, cond_dim=3)
+    sd = {k: torch.tensor(v) for k, v in weights0.items()}
+    sd["sigmas"] = torch.tensor(syn.sigmas_buffer())
+    model.load_state_dict(sd)
+    ema = ExponentialMovingAverage(model.parameters(), decay=0.9999)
+    os.makedirs(tmp_path / "ckpt")
+    torch.save({"model_state_dict": {"module." + k: v for k, v in model.state_dict().items()},
+                "ema": ema.state_dict(), "step": 1500}, tmp_path / "ckpt" / "checkpoint_1500.pth")
+    monkeypatch.chdir(tmp_path)
+    a = om.parse_args(["prog", "--config", str(cfg_file), "--ckpt_dir", "ckpt", "--ckpt_name", "checkpoint_1500.pth",
+                       "--hypo", "2", "--oil_iterations", "60"] + flags)
+    p1, p2 = om.main(a)
+    d1, d2 = abs(p1 - float(g[f"{tag}_mpjpe"])), abs(p2 - float(g[f"{tag}_pa_mpjpe"]))
+    print(f"files[{tag}]: MPJPE {p1:.6f} vs {float(g[f'{tag}_mpjpe']):.6f} (d {d1 * 1e3:.4f} mm), "
+          f"PA {p2:.6f} vs {float(g[f'{tag}_pa_mpjpe']):.6f} (d {d2 * 1e3:.4f} mm)")
+    assert d1 < 5e-5 and d2 < 5e-5

@@ -348,8 +348,98 @@ def gen_driver():
          batch_results=batch_results, mpjpe=np.float64(p1), pa_mpjpe=np.float64(p2))
 
 
+
+# ------------------------------------------------------------------ dataset files
+
+ASSETS = os.path.join(OUT, "assets")
+PW3D_ORDER = [5, 2, 6, 3, 11, 14, 12, 15, 13, 16, 1, 4, 8, 10, 0, 7, 9]
+
+
+def write_assets(N=20, seed=77):
+    """Small files in the formats the reference's readers parse (h36m.py:206-263, pw3d.py:177-227), filled
+    with seeded synthetic poses.  They are DATA made here, not reference content."""
+    import pickle
+    d = syn.make_poses(N, seed=seed, conf_mode="uniform", dtype3d=np.float64)
+    K = d["camera_param"].astype(np.float64)
+    mm = d["db_3d"] * 1000.0
+    g = np.random.Generator(np.random.Philox(key=[seed, 99]))
+    items = []
+    for i in range(N):
+        img = np.concatenate([d["db_2d"][i, :, :2].astype(np.float64), mm[i, :, 2:3] - mm[i, 0:1, 2:3]], axis=1)
+        items.append(dict(joint_3d_camera=mm[i], joint_3d_image=img,
+                          camera_param=dict(fx=np.array([K[i, 0, 0]]), fy=np.array([K[i, 1, 1]]),
+                                            cx=np.float64(K[i, 0, 2]), cy=np.float64(K[i, 1, 2])),
+                          action=int(2 + i % 15), subaction=1 + i % 2, subject=9 + 2 * (i % 2), cam_id=i % 4,
+                          image_path=f"s_{9 + 2 * (i % 2):02d}_act_{2 + i % 15:02d}_subact_01_ca_{i % 4 + 1:02d}_{i:06d}.jpg"))
+    os.makedirs(os.path.join(ASSETS, "h36m"), exist_ok=True)
+    os.makedirs(os.path.join(ASSETS, "3dpw"), exist_ok=True)
+    with open(os.path.join(ASSETS, "h36m", "h36m_test.pkl"), "wb") as f:
+        pickle.dump(items, f, protocol=4)
+    det = d["db_2d"][:, :, :2].astype(np.float64) + 3.0 * g.standard_normal((N, 17, 2))
+    dt = dict(test=dict(joint3d_image=np.concatenate([det, np.zeros((N, 17, 1))], axis=2),
+                        confidence=d["db_2d"][:, :, 2:3].astype(np.float64)))
+    with open(os.path.join(ASSETS, "h36m", "h36m_sh_dt_ft.pkl"), "wb") as f:
+        pickle.dump(dt, f, protocol=4)
+    # 3DPW: joints stored in the file's own order (order_change scatters file joint i to H36M joint ORDER[i])
+    pose = d["db_3d"]                                     # H36M order, metres, camera frame
+    in_file = pose[:, PW3D_ORDER, :]
+    root = in_file[:, 14, :] + 0.01 * g.standard_normal((N, 3))
+    rel = np.concatenate([in_file - root[:, None, :], np.ones((N, 17, 1))], axis=2)
+    cam = dict(f=np.stack([K[:, 0, 0], K[:, 1, 1]], 1), c=np.stack([K[:, 0, 2], K[:, 1, 2]], 1))
+    np.savez_compressed(os.path.join(ASSETS, "3dpw", "pw3d_test.npz"), keypoints3d17_relative=rel, root_cam=root,
+                        cam_param=np.array(cam, dtype=object), image_width=np.full(N, 1920), image_height=np.full(N, 1080),
+                        image_path=np.array([f"imageFiles/seq_{i % 3}/image_{i:05d}.jpg" for i in range(N)]))
+
+
+def gen_datasets():
+    write_assets()
+    out = {}
+    for tag, kw in (("gt", dict(gt2d=True)), ("dt", dict(gt2d=False)), ("gt_s3", dict(gt2d=True, sample_interval=3)),
+                    ("dt_rel", dict(gt2d=False, abs_coord=False))):
+        kw.setdefault("abs_coord", True)
+        ds = H36MDataset3D(os.path.join(ASSETS, "h36m"), "test", flip=False, **kw)
+        out[f"h36m_{tag}_db_2d"], out[f"h36m_{tag}_db_3d"], out[f"h36m_{tag}_camera_param"] = ds.db_2d, ds.db_3d, ds.camera_param
+        out[f"h36m_{tag}_actions"] = np.array([it["action"] for it in ds.gt_dataset])
+        out[f"h36m_{tag}_len"] = np.int64(len(ds))
+    for tag, kw in (("abs", dict(abs_coord=True)), ("abs_s4", dict(abs_coord=True, sample_interval=4)), ("rel", dict(abs_coord=False))):
+        ds = PW3D(os.path.join(ASSETS, "3dpw"), "test", gt2d=True, flip=False, **kw)
+        out[f"pw3d_{tag}_db_2d"], out[f"pw3d_{tag}_db_3d"], out[f"pw3d_{tag}_camera_param"] = ds.db_2d, ds.db_3d, ds.camera_param
+        out[f"pw3d_{tag}_w"], out[f"pw3d_{tag}_h"] = ds.w, ds.h
+        out[f"pw3d_{tag}_image_name"] = np.array([str(s) for s in ds.image_name])
+    save("datasets", **out)
+
+
+def gen_driver_files():
+    """The file-driven evaluation: reference readers on tests/golden/assets -> the re-driven opt_main loop
+    (opt_main.py:166-224) with H36M settings -> H36MDataset3D.eval_multi (action-wise).  N=20, H=2, S=60."""
+    write_assets()
+    w = syn.make_weights(seed=0)
+    m = ref_model(w)
+    H, S = 2, 60
+    out = {}
+    for tag, gt2d in (("gt", True), ("dt", False)):
+        ds = H36MDataset3D(os.path.join(ASSETS, "h36m"), "test", gt2d=gt2d, abs_coord=True, sample_interval=None, flip=False)
+        gt_3d, K, gt_2d = ds.db_3d, ds.camera_param, ds.db_2d
+        cl = syn.make_clusters(H, seed=8)
+        batch_results = []
+        for sid in range(H):
+            noisy = (torch.ones_like(torch.tensor(gt_3d)) * torch.tensor(cl - cl[:, 0:1, :])[sid:sid + 1]).float()
+            c2 = np.asarray(gt_2d, dtype=np.float32)
+            r = run_ref_ipo(noisy.numpy(), c2[:, :, :2], K, "z", [0, 1, 4], 3.0, 0.5, 2.0, 500)
+            x = torch.tensor(r["R"]).bmm(noisy.permute(0, 2, 1)).permute(0, 2, 1).contiguous().numpy()
+            res, _, _ = run_ref_oil(m, x, c2[:, :, :2], c2[:, :, 2], K, r["T"], S, [])
+            batch_results.append(res)
+        batch_results = np.swapaxes(np.array(batch_results), 0, 1)
+        out[f"{tag}_batch_results"] = batch_results
+        out[f"{tag}_mpjpe"] = np.float64(ds.eval_multi(batch_results, protocol2=False))
+        out[f"{tag}_pa_mpjpe"] = np.float64(ds.eval_multi(batch_results, protocol2=True))
+    out["clusters"] = syn.make_clusters(H, seed=8)
+    save("driver_files", **out)
+
+
 GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo, oil=gen_oil,
-            eval=gen_eval, driver=gen_driver)
+            eval=gen_eval, driver=gen_driver, datasets=gen_datasets,
+            driver_files=gen_driver_files)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -3,8 +3,9 @@
 
 File parsing follows the reference's `read_data` (:206-263): `h36m_<subset>.pkl` is a list of dicts with
 `joint_3d_camera` (mm), `joint_3d_image`, `camera_param{fx,fy,cx,cy}`, `action`, `image_path`; detections
-come from `h36m_sh_dt_ft.pkl`.  Those assets are Google-Drive downloads that are not available offline,
-so the parser is exercised only through `from_arrays` in the tests.
+come from `h36m_sh_dt_ft.pkl`.  The real assets are Google-Drive downloads that are not available offline;
+tests/test_dataset_files.py checks the parser bit for bit against the reference's reader on small synthetic
+files of the same format (tests/golden/assets).
 """
 import os
 import pickle
@@ -74,6 +75,7 @@ class H36MDataset3D:
             labels_3d = labels_3d - labels_3d[:, 0:1]
         labels_3d = labels_3d / 1000.0
         if self.gt2d:
+            # dtype as in the reference: float32 pixels, widened to float64 by the appended confidence column
             data_2d = labels_img[..., :2].copy()
             if self.read_confidence:
                 data_2d = np.concatenate((data_2d, np.ones((n, 17, 1))), axis=-1)
@@ -83,7 +85,8 @@ class H36MDataset3D:
             data_2d = dt[self.subset]["joint3d_image"][:, :, :2].copy()
             if self.read_confidence:
                 data_2d = np.concatenate((data_2d, dt[self.subset]["confidence"].copy()), axis=-1)
-        return data_2d.astype(np.float32), labels_3d, gt_dataset, cams
+            data_2d = data_2d.astype(np.float32)
+        return data_2d, labels_3d, gt_dataset, cams
 
     # ------------------------------------------------------------------ metric
     def gt_centred(self):

@@ -3,7 +3,8 @@
 `read_data` follows the reference (:177-227): `pw3d_<subset>.npz` with `keypoints3d17_relative`,
 `root_cam`, `cam_param{f,c}`, `image_width/height/path`; joints are re-ordered to the H36M layout with
 `order` (:76,170-175) and the 2D input is the projection of the 3D label (confidence column = 1).  The
-asset is not available offline, so the parser is exercised only through `from_arrays` in the tests.
+real asset is not available offline; tests/test_dataset_files.py checks the parser bit for bit against the
+reference's reader on a small synthetic file of the same format (tests/golden/assets).
 """
 import os
 
