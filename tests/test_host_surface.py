@@ -25,8 +25,8 @@ def test_module_paths_of_the_reference_exist():
     import run.inference
     for m in (run.opt_main, run.inference):
         assert callable(m.parse_args) and callable(m.main)
-    assert sorted(sampling._PREDICTORS) == ["euler_maruyama", "none", "reverse_diffusion"]
-    assert sorted(sampling._CORRECTORS) == ["langevin", "none"]
+    assert sorted(sampling._PREDICTORS) == ["ancestral_sampling", "euler_maruyama", "none", "reverse_diffusion"]
+    assert sorted(sampling._CORRECTORS) == ["ald", "langevin", "none"]
 
 
 def test_configs_hold_the_reference_values():

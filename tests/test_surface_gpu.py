@@ -203,3 +203,53 @@ def test_opt_main_from_files_matches_reference(tmp_path, golden, weights0, tag, 
     print(f"files[{tag}]: MPJPE {p1:.6f} vs {float(g[f'{tag}_mpjpe']):.6f} (d {d1 * 1e3:.4f} mm), "
           f"PA {p2:.6f} vs {float(g[f'{tag}_pa_mpjpe']):.6f} (d {d2 * 1e3:.4f} mm)")
     assert d1 < 5e-5 and d2 < 5e-5
+
+
+PC_GENERIC_CASES = [
+    # tag, sde, continuous, predictor, corrector, probability_flow, noise_removal, t   (tools/gen_golden.py)
+    ("vp_rd_langevin", "vpsde", True, "reverse_diffusion", "langevin", False, True, 0.31),
+    ("vp_anc_none_disc", "vpsde", False, "ancestral_sampling", "none", False, True, 0.52),
+    ("vp_em_none_pf", "vpsde", True, "euler_maruyama", "none", True, True, 0.2),
+    ("ve_rd_ald", "vesde", True, "reverse_diffusion", "ald", False, True, 0.4),
+    ("ve_anc_langevin", "vesde", True, "ancestral_sampling", "langevin", False, False, 0.15),
+    ("subvp_em_none_sde", "subvpsde", True, "euler_maruyama", "none", False, False, 0.07),
+    ("subvp_rd_none", "subvpsde", True, "reverse_diffusion", "none", False, True, 0.05),
+]
+
+
+class DetNoise:
+    """torch.randn_like replacement shared with the capture script: numpy Philox, keyed by the call count."""
+
+    def __init__(self):
+        self.calls = 0
+
+    def __call__(self, x):
+        g = np.random.Generator(np.random.Philox(key=[555, self.calls]))
+        self.calls += 1
+        return torch.tensor(g.standard_normal(tuple(x.shape)), dtype=x.dtype, device=x.device)
+
+
+@pytest.mark.parametrize("case", PC_GENERIC_CASES, ids=[c[0] for c in PC_GENERIC_CASES])
+def test_pc_sampler_other_sdes_and_update_rules(model, golden, monkeypatch, case):
+    """the config-reachable but non-shipped SDE / predictor / corrector combinations behind
+    get_sampling_fn, with the score network on the HIP path, against the reference's pc_sampler (same noise)."""
+    from lib.algorithms.advanced import sampling, sde_lib
+    from run._driver import load_config
+    tag, sname, cont, pred, corr, pf, denoise, t = case
+    p = golden("pc_generic")
+    cfg = load_config(cfg_path("h36m"))
+    cfg.training.sde, cfg.training.continuous = sname, cont
+    cfg.sampling.predictor, cfg.sampling.corrector, cfg.sampling.probability_flow = pred, corr, pf
+    cfg.sampling.noise_removal = denoise
+    sde = dict(vpsde=lambda: sde_lib.VPSDE(0.1, 20.0, 1000, 1.0), vesde=lambda: sde_lib.VESDE(0.01, 50.0, 1000, 1.0),
+               subvpsde=lambda: sde_lib.subVPSDE(0.1, 20.0, 1000, 1.0))[sname]()
+    fn = sampling.get_sampling_fn(cfg, sde, (8, 17, 3), lambda v: v, 0.01, device=torch.device("cuda"))
+    monkeypatch.setattr(torch, "randn_like", DetNoise())
+    trajs, res = fn(model, condition=torch.zeros(8, 17, 2, device="cuda"), denoise_x=dev(p["x"]),
+                    t=torch.tensor(t), t_step=3)
+    assert isinstance(res, torch.Tensor) == bool(p[f"{tag}_res_is_tensor"])
+    res = res.cpu().numpy() if isinstance(res, torch.Tensor) else res
+    scale = max(1.0, float(np.abs(p[f"{tag}_res"]).max()))
+    d1, d2 = np.abs(trajs - p[f"{tag}_trajs"]).max(), np.abs(res - p[f"{tag}_res"]).max()
+    print(f"pc_generic[{tag}]: max|d trajs| {d1:.2e}  max|d res| {d2:.2e}  (magnitude {scale:.2f})")
+    assert d1 < 1e-6 * scale and d2 < 1e-6 * scale      # fp32 round-off of the HIP score network

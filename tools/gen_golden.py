@@ -437,9 +437,136 @@ def gen_driver_files():
     save("driver_files", **out)
 
 
+
+# ------------------------------------------------------------------ other SDEs / update rules
+
+def sampler_cases():
+    """(sde name, ctor kwargs) x (predictor, probability_flow) and x (corrector) combinations captured below."""
+    sdes = [("vpsde", dict(beta_min=0.1, beta_max=20.0, N=1000, T=1.0)),
+            ("subvpsde", dict(beta_min=0.1, beta_max=20.0, N=1000, T=1.0)),
+            ("vesde", dict(sigma_min=0.01, sigma_max=50.0, N=1000, T=1.0))]
+    preds = [("euler_maruyama", False), ("euler_maruyama", True), ("reverse_diffusion", False),
+             ("reverse_diffusion", True), ("ancestral_sampling", False)]
+    corrs = ["langevin", "ald"]
+    return sdes, preds, corrs
+
+
+def sampler_inputs():
+    g = np.random.Generator(np.random.Philox(key=[2024, 3]))
+    x = g.standard_normal((6, 17, 3)).astype(np.float32)
+    cond = g.standard_normal((6, 17, 3)).astype(np.float32)
+    t = np.array([0.9, 0.5, 0.1, 0.013, 0.0005, 0.7], np.float32)     # 0.0005 -> discrete step 0 (VE adjacent sigma = 0)
+    return x, cond, t
+
+
+class DetNoise:
+    """Replacement for torch.randn_like during capture and test: numpy Philox, independent of the torch build."""
+
+    def __init__(self):
+        self.calls = 0
+
+    def __call__(self, x):
+        g = np.random.Generator(np.random.Philox(key=[555, self.calls]))
+        self.calls += 1
+        return torch.tensor(g.standard_normal(tuple(x.shape)), dtype=x.dtype)
+
+
+def analytic_score(x, t, condition, mask):
+    return -(x - 0.3 * condition) / (0.5 + t)[:, None, None]
+
+
+def gen_samplers():
+    sdes, preds, corrs = sampler_cases()
+    xn, cn, tn = sampler_inputs()
+    x, cond, t = torch.tensor(xn), torch.tensor(cn), torch.tensor(tn)
+    mask = torch.zeros_like(x)
+    out = dict(x=xn, cond=cn, t=tn)
+    orig = torch.randn_like
+    for name, kw in sdes:
+        cls = dict(vpsde=sde_lib.VPSDE, subvpsde=sde_lib.subVPSDE, vesde=sde_lib.VESDE)[name]
+        sde = cls(**kw)
+        out[f"{name}_drift"], out[f"{name}_diffusion"] = [a.numpy() for a in sde.sde(x, t)]
+        out[f"{name}_mean"], out[f"{name}_std"] = [a.numpy() for a in sde.marginal_prob(x, t)]
+        f, G = sde.discretize(x, t)
+        out[f"{name}_disc_f"], out[f"{name}_disc_G"] = f.numpy(), G.numpy()
+        for pf in (False, True):
+            r = sde.reverse(analytic_score, pf)
+            d, g_ = r.sde(x, t, cond, mask)
+            out[f"{name}_rsde_drift_pf{int(pf)}"], out[f"{name}_rsde_diffusion_pf{int(pf)}"] = d.numpy(), g_.numpy()
+            f, G = r.discretize(x, t, cond, mask)
+            out[f"{name}_rdisc_f_pf{int(pf)}"], out[f"{name}_rdisc_G_pf{int(pf)}"] = f.numpy(), G.numpy()
+        for pname, pf in preds:
+            key = f"{name}_pred_{pname}_pf{int(pf)}"
+            torch.randn_like = DetNoise()
+            try:
+                xn_, xm = sampling.get_predictor(pname)(sde, analytic_score, pf).update_fn(x, t, cond, mask)
+                out[key + "_x"], out[key + "_mean"] = xn_.numpy(), xm.numpy()
+            except (NotImplementedError, AssertionError, AttributeError) as e:
+                out[key + "_raises"] = np.array(type(e).__name__)
+            finally:
+                torch.randn_like = orig
+        for cname in corrs:
+            key = f"{name}_corr_{cname}"
+            torch.randn_like = DetNoise()
+            try:
+                xn_, xm = sampling.get_corrector(cname)(sde, analytic_score, 0.16, 2).update_fn(x, t, cond, mask)
+                out[key + "_x"], out[key + "_mean"] = xn_.numpy(), xm.numpy()
+            except (NotImplementedError, AssertionError, AttributeError) as e:
+                out[key + "_raises"] = np.array(type(e).__name__)
+            finally:
+                torch.randn_like = orig
+    save("samplers", **out)
+
+
+
+PC_GENERIC_CASES = [
+    # tag, sde, continuous, predictor, corrector, probability_flow, noise_removal, t
+    ("vp_rd_langevin", "vpsde", True, "reverse_diffusion", "langevin", False, True, 0.31),
+    ("vp_anc_none_disc", "vpsde", False, "ancestral_sampling", "none", False, True, 0.52),
+    ("vp_em_none_pf", "vpsde", True, "euler_maruyama", "none", True, True, 0.2),
+    ("ve_rd_ald", "vesde", True, "reverse_diffusion", "ald", False, True, 0.4),
+    ("ve_anc_langevin", "vesde", True, "ancestral_sampling", "langevin", False, False, 0.15),
+    ("subvp_em_none_sde", "subvpsde", True, "euler_maruyama", "none", False, False, 0.07),
+    ("subvp_rd_none", "subvpsde", True, "reverse_diffusion", "none", False, True, 0.05),
+]
+
+
+def make_sde(name):
+    if name == "vpsde":
+        return sde_lib.VPSDE(beta_min=0.1, beta_max=20.0, N=1000, T=1.0)
+    if name == "vesde":
+        return sde_lib.VESDE(sigma_min=0.01, sigma_max=50.0, N=1000, T=1.0)
+    return sde_lib.subVPSDE(beta_min=0.1, beta_max=20.0, N=1000, T=1.0)
+
+
+def gen_pc_generic():
+    """get_sampling_fn with the real network for the config-reachable, non-shipped SDE / predictor / corrector
+    combinations (one pc_sampler call each; noise from DetNoise)."""
+    m = ref_model(syn.make_weights(seed=0))
+    g = np.random.Generator(np.random.Philox(key=[7, 12]))
+    x = (0.3 * g.standard_normal((8, 17, 3))).astype(np.float32)
+    out = dict(x=x)
+    orig = torch.randn_like
+    for tag, sname, cont, pred, corr, pf, denoise, t in PC_GENERIC_CASES:
+        cfg = ref_config()
+        cfg.training.sde, cfg.training.continuous = sname, cont
+        cfg.sampling.predictor, cfg.sampling.corrector, cfg.sampling.probability_flow = pred, corr, pf
+        cfg.sampling.noise_removal = denoise
+        fn = sampling.get_sampling_fn(cfg, make_sde(sname), (8, 17, 3), lambda v: v, 0.01, device=torch.device("cpu"))
+        torch.randn_like = DetNoise()
+        try:
+            trajs, res = fn(m, condition=torch.zeros(8, 17, 2), denoise_x=torch.tensor(x), t=torch.tensor(t), t_step=3)
+        finally:
+            torch.randn_like = orig
+        out[f"{tag}_trajs"] = trajs
+        out[f"{tag}_res"] = res if isinstance(res, np.ndarray) else res.numpy()
+        out[f"{tag}_res_is_tensor"] = np.bool_(not isinstance(res, np.ndarray))
+    save("pc_generic", **out)
+
+
 GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo, oil=gen_oil,
             eval=gen_eval, driver=gen_driver, datasets=gen_datasets,
-            driver_files=gen_driver_files)
+            driver_files=gen_driver_files, samplers=gen_samplers, pc_generic=gen_pc_generic)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -85,6 +85,32 @@ class ReverseDiffusionPredictor(Predictor):
         return x_mean + G[:, None, None] * torch.randn_like(x), x_mean
 
 
+@register_predictor(name="ancestral_sampling")
+class AncestralSamplingPredictor(Predictor):
+    """Ancestral sampling for the discrete VE / VP chains (reference :208-248); no probability-flow form."""
+
+    def __init__(self, sde, score_fn, probability_flow=False):
+        super().__init__(sde, score_fn, probability_flow)
+        if not isinstance(sde, (sde_lib.VPSDE, sde_lib.VESDE)):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+        assert not probability_flow, "Probability flow not supported by ancestral sampling"
+
+    def update_fn(self, x, t, condition, mask):
+        sde = self.sde
+        step = (t * (sde.N - 1) / sde.T).long()
+        if isinstance(sde, sde_lib.VESDE):
+            sig = sde.discrete_sigmas.to(t.device)
+            s2 = sig[step] ** 2
+            p2 = torch.where(step == 0, torch.zeros_like(t), sig[step - 1]) ** 2
+            x_mean = x + self.score_fn(x, t, condition, mask) * (s2 - p2)[:, None, None]
+            std = torch.sqrt(p2 * (s2 - p2) / s2)
+        else:
+            beta = sde.discrete_betas.to(t.device)[step]
+            x_mean = (x + beta[:, None, None] * self.score_fn(x, t, condition, mask)) / torch.sqrt(1.0 - beta)[:, None, None]
+            std = torch.sqrt(beta)
+        return x_mean + std[:, None, None] * torch.randn_like(x), x_mean
+
+
 @register_predictor(name="none")
 class NonePredictor(Predictor):
     def __init__(self, sde, score_fn, probability_flow=False):
@@ -103,14 +129,25 @@ class NoneCorrector(Corrector):
         return x, x
 
 
+def _corrector_alpha(sde, t):
+    """alpha_i of the discrete VP chain, 1 for VE (reference :275-279).  The reference takes the VP branch for
+    subVPSDE too, which has no `alphas` table: that combination raises AttributeError there and here."""
+    if isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE)):
+        return sde.alphas.to(t.device)[(t * (sde.N - 1) / sde.T).long()]
+    return torch.ones_like(t)
+
+
+class _CheckedCorrector(Corrector):
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__(sde, score_fn, snr, n_steps)
+        if not isinstance(sde, (sde_lib.VPSDE, sde_lib.VESDE, sde_lib.subVPSDE)):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+
+
 @register_corrector(name="langevin")
-class LangevinCorrector(Corrector):
+class LangevinCorrector(_CheckedCorrector):
     def update_fn(self, x, t, condition, mask):
-        sde = self.sde
-        if isinstance(sde, sde_lib.VPSDE):
-            alpha = sde.alphas.to(t.device)[(t * (sde.N - 1) / sde.T).long()]
-        else:
-            alpha = torch.ones_like(t)
+        alpha = _corrector_alpha(self.sde, t)
         x_mean = x
         for _ in range(self.n_steps):
             grad = self.score_fn(x, t, condition, mask)
@@ -120,6 +157,23 @@ class LangevinCorrector(Corrector):
             step = (self.snr * nn_ / gn) ** 2 * 2 * alpha
             x_mean = x + step[:, None, None] * grad
             x = x_mean + torch.sqrt(step * 2)[:, None, None] * noise
+        return x, x_mean
+
+
+@register_corrector(name="ald")
+class AnnealedLangevinDynamics(_CheckedCorrector):
+    """Annealed Langevin dynamics of NCSN (reference :300-331): step size from the marginal std, not the norms."""
+
+    def update_fn(self, x, t, condition, mask):
+        alpha = _corrector_alpha(self.sde, t)
+        std = self.sde.marginal_prob(x, t)[1]
+        x_mean = x
+        for _ in range(self.n_steps):
+            grad = self.score_fn(x, t, condition, mask)
+            noise = torch.randn_like(x)
+            step = (self.snr * std) ** 2 * 2 * alpha
+            x_mean = x + step[:, None, None] * grad
+            x = x_mean + noise * torch.sqrt(step * 2)[:, None, None]
         return x, x_mean
 
 
@@ -182,6 +236,6 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
             trajs = np.stack([x_new.cpu().numpy()], axis=0)
             x_mean_np = x_mean.cpu().numpy()
             trajs[-1] = x_mean_np
-            return trajs, (x_mean_np if denoise else x_new.cpu().numpy())
+            return trajs, (x_mean_np if denoise else x_new)     # the reference hands back the tensor here (:527)
 
     return pc_sampler

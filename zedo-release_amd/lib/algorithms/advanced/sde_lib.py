@@ -144,7 +144,8 @@ class VESDE(SDE):
 
     def sde(self, x, t):
         sigma = self.sigma_min * (self.sigma_max / self.sigma_min) ** t
-        g = sigma * float(np.sqrt(2 * (np.log(self.sigma_max) - np.log(self.sigma_min))))
+        # the constant is rounded to fp32 before the square root, as in the reference (:241-242)
+        g = sigma * torch.sqrt(torch.tensor(2 * (np.log(self.sigma_max) - np.log(self.sigma_min)), device=t.device))
         return torch.zeros_like(x), g
 
     def marginal_prob(self, x, t):
@@ -152,3 +153,15 @@ class VESDE(SDE):
 
     def prior_sampling(self, shape):
         return torch.randn(*shape) * self.sigma_max
+
+    def prior_logp(self, z):
+        n = np.prod(z.shape[1:])
+        s2 = self.sigma_max ** 2
+        return -n / 2.0 * np.log(2 * np.pi * s2) - torch.sum(z.reshape(z.shape[0], -1) ** 2, dim=1) / (2 * s2)
+
+    def discretize(self, x, t):
+        """SMLD discretisation (reference :253-261): f = 0, G^2 = sigma_i^2 - sigma_{i-1}^2 (sigma_{-1} = 0)."""
+        step = (t * (self.N - 1) / self.T).long()
+        sig = self.discrete_sigmas.to(t.device)
+        prev = torch.where(step == 0, torch.zeros_like(t), sig[step - 1])
+        return torch.zeros_like(x), torch.sqrt(sig[step] ** 2 - prev ** 2)
