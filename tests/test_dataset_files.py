@@ -58,3 +58,41 @@ def test_missing_files_fail_loudly(tmp_path):
         H36MDataset3D(str(tmp_path), "test")
     with pytest.raises(FileNotFoundError):
         PW3D(str(tmp_path), "test")
+
+
+@pytest.mark.parametrize("tag,kw", [("all", dict()), ("s2", dict(sample_interval=2)),
+                                    ("rel_s3", dict(sample_interval=3, abs_coord=False))])
+def test_3dhp_reader_matches_the_reference(golden, tag, kw):
+    """mpii3d_test.pkl -> arrays, valid-frame filter, action relabelling (mpii3dHP.py:236-312)."""
+    from lib.dataset.mpii3dHP import MPII3DHP
+    g = golden("hp3d_ski")
+    kw = dict(dict(abs_coord=True), **kw)
+    ds = MPII3DHP(os.path.join(ASSETS, "3dhp"), "test", gt2d=True, flip=False, **kw)
+    for name in ("db_2d", "db_3d", "camera_param", "valid_id"):
+        assert same(getattr(ds, name), g[f"hp_{tag}_{name}"]), (tag, name, getattr(ds, name).dtype)
+    assert [d["action"] for d in ds.gt_dataset] == list(g[f"hp_{tag}_actions"])
+    assert [str(s) for s in ds.image_path] == [str(s) for s in g[f"hp_{tag}_image_path"]]
+    with pytest.raises(NotImplementedError):
+        MPII3DHP(os.path.join(ASSETS, "3dhp"), "test", gt2d=False)
+
+
+def test_pck_auc_helpers_match_the_reference(golden):
+    from lib.algorithms.advanced.utils import compute_AUC, compute_PCK
+    g = golden("hp3d_ski")
+    a, b = g["pck_gts"], g["pck_preds"]
+    assert compute_PCK(a, b) == float(g["pck_150"])
+    assert compute_PCK(a, b, eval_joints=[1, 2, 3, 14, 15, 16], threshold=50) == float(g["pck_50_joints"])
+    assert compute_AUC(a, b) == float(g["auc"])
+    assert compute_AUC(a, b, eval_joints=[0, 7, 8, 9, 10]) == float(g["auc_joints"])
+
+
+def test_skipose_reader_needs_h5py_and_says_so(tmp_path):
+    from lib.dataset.skiPose import skiPose
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            skiPose(str(tmp_path), "test")
+    else:
+        with pytest.raises(OSError):
+            skiPose(str(tmp_path), "test")

@@ -20,6 +20,9 @@ def test_module_paths_of_the_reference_exist():
     from lib.dataset.h36m import H36MDataset3D                # noqa: F401
     from lib.dataset.pw3d import PW3D                          # noqa: F401
     from lib.dataset.custom import CustomDataset               # noqa: F401
+    from lib.dataset.mpii3dHP import MPII3DHP                  # noqa: F401
+    from lib.dataset.skiPose import skiPose                    # noqa: F401
+    from lib.algorithms.advanced.utils import compute_PCK, compute_AUC   # noqa: F401
     from lib.utils.transforms import procrustes, align_to_gt   # noqa: F401
     import run.opt_main
     import run.inference
@@ -31,8 +34,8 @@ def test_module_paths_of_the_reference_exist():
 
 def test_configs_hold_the_reference_values():
     from run._driver import load_config
-    h, p, w = (load_config(cfg_path(n)) for n in ("h36m", "pw3d", "wild"))
-    for c in (h, p, w):
+    h, p, w, d, k = (load_config(cfg_path(n)) for n in ("h36m", "pw3d", "wild", "3dhp", "ski"))
+    for c in (h, p, w, d, k):
         assert c.training.sde == "subvpsde" and c.sampling.method == "pc"
         assert c.sampling.predictor == "euler_maruyama" and c.sampling.corrector == "none"
         assert c.model.t == 0.1 and c.model.beta_min == 0.1 and c.model.beta_max == 20.0 and c.model.num_scales == 1000
@@ -40,7 +43,9 @@ def test_configs_hold_the_reference_values():
         assert c.sampling.noise_removal is True
     assert (h.ZeDO.IPO_keylist, h.ZeDO.IPO_T, h.ZeDO.IPO_minScaleT, h.ZeDO.sample, h.ZeDO.batch) == ([0, 1, 4], 3, 0.5, 640, 886)
     assert (p.ZeDO.IPO_keylist, p.ZeDO.IPO_T, p.ZeDO.IPO_minScaleT, p.ZeDO.sample, p.ZeDO.batch) == (list(range(17)), 8, 0.2, 35, 1015)
-    assert (h.data.dataset, p.data.dataset, w.data.dataset) == ("h36m", "3dpw", "wild")
+    assert (d.ZeDO.IPO_keylist, d.ZeDO.IPO_T, d.ZeDO.RotAxes, d.ZeDO.sample, d.ZeDO.batch) == ([0, 1, 4], 3, "z", 3, 959)
+    assert (k.ZeDO.IPO_keylist, k.ZeDO.IPO_T, k.ZeDO.RotAxes, k.ZeDO.sample, k.ZeDO.batch) == (list(range(17)), 20, "y", 1, 1716)
+    assert [c.data.dataset for c in (h, p, w, d, k)] == ["h36m", "3dpw", "wild", "3dhp", "ski"]
 
 
 def test_flags_match_the_reference():

@@ -253,3 +253,32 @@ def test_pc_sampler_other_sdes_and_update_rules(model, golden, monkeypatch, case
     d1, d2 = np.abs(trajs - p[f"{tag}_trajs"]).max(), np.abs(res - p[f"{tag}_res"]).max()
     print(f"pc_generic[{tag}]: max|d trajs| {d1:.2e}  max|d res| {d2:.2e}  (magnitude {scale:.2f})")
     assert d1 < 1e-6 * scale and d2 < 1e-6 * scale      # fp32 round-off of the HIP score network
+
+
+def test_3dhp_and_ski_eval_multi(golden):
+    """3DHP best-of-H action-wise error + PCK / AUC of the selected hypotheses, SkiPose mean error,
+    against the reference's eval_multi on the same file / predictions (tools/gen_golden.py::gen_3dhp_ski)."""
+    from lib.dataset.mpii3dHP import MPII3DHP
+    from lib.dataset.skiPose import skiPose
+    g = golden("hp3d_ski")
+    ds = MPII3DHP(os.path.join(ROOT, "tests", "golden", "assets", "3dhp"), "test", gt2d=True, abs_coord=True,
+                  sample_interval=2, flip=False)
+    preds = g["hp_preds"]
+    N, H = preds.shape[:2]
+    rows = dev(preds).permute(1, 0, 2, 3).reshape(H * N, 17, 3).contiguous()
+    for k, proto in (("p1", False), ("p2", True)):
+        for form in (preds, ("rows", rows)):
+            err = ds.eval_multi(form, protocol2=proto, print_verbose=True)
+            assert abs(err - float(g[f"hp_{k}"])) < 1e-7
+            assert ds.last_pck == float(g[f"hp_{k}_pck"]) and abs(ds.last_auc - float(g[f"hp_{k}_auc"])) < 1e-12
+    sk = skiPose.from_arrays(np.zeros((N, 17, 3), np.float32), g["ski_db_3d"], np.tile(np.eye(3, dtype=np.float32), (N, 1, 1)))
+    assert abs(sk.eval_multi(preds, protocol2=False) - float(g["ski_p1"])) < 1e-7
+    assert abs(sk.eval_multi(("rows", rows), protocol2=True) - float(g["ski_p2"])) < 1e-7
+
+
+def test_opt_main_synthetic_3dhp_and_ski():
+    import run.opt_main as om
+    for name in ("3dhp", "ski"):
+        a = om.parse_args(["prog", "--config", cfg_path(name), "--hypo", "2", "--synthetic", "28", "--oil_iterations", "10"])
+        p1, p2 = om.main(a)
+        assert np.isfinite(p1) and np.isfinite(p2) and p2 <= p1 + 1e-9

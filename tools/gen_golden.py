@@ -564,9 +564,78 @@ def gen_pc_generic():
     save("pc_generic", **out)
 
 
+
+# ------------------------------------------------------------------ 3DHP / SkiPose
+
+def write_3dhp_asset(N=45, seed=91):
+    import pickle
+    d = syn.make_poses(N, seed=seed, dtype3d=np.float64)
+    K = d["camera_param"].astype(np.float64)
+    mm = d["db_3d"] * 1000.0
+    items = []
+    for i in range(N):
+        j2 = np.concatenate([d["db_2d"][i, :, :2].astype(np.float64), np.zeros((17, 1))], axis=1)
+        items.append(dict(joint_3d_camera=mm[i], joint_2d=j2, w=2048, h=2048,
+                          camera_param=dict(fx=K[i, 0, 0], fy=K[i, 1, 1], cx=K[i, 0, 2], cy=K[i, 1, 2]),
+                          imageid=f"TS{1 + i % 6}/imageSequence/img_{i:06d}.jpg", valid_i=float(i % 5 != 3),
+                          action=1 + i % 7))
+    os.makedirs(os.path.join(ASSETS, "3dhp"), exist_ok=True)
+    with open(os.path.join(ASSETS, "3dhp", "mpii3d_test.pkl"), "wb") as f:
+        pickle.dump(items, f, protocol=4)
+
+
+def gen_3dhp_ski():
+    import contextlib
+    import io
+    import re
+    from lib.dataset.mpii3dHP import MPII3DHP
+    from lib.dataset.skiPose import skiPose
+    write_3dhp_asset()
+    out = {}
+    for tag, kw in (("all", dict()), ("s2", dict(sample_interval=2)), ("rel_s3", dict(sample_interval=3, abs_coord=False))):
+        kw.setdefault("abs_coord", True)
+        ds = MPII3DHP(os.path.join(ASSETS, "3dhp"), "test", gt2d=True, flip=False, **kw)
+        out[f"hp_{tag}_db_2d"], out[f"hp_{tag}_db_3d"], out[f"hp_{tag}_camera_param"] = ds.db_2d, ds.db_3d, ds.camera_param
+        out[f"hp_{tag}_valid_id"] = ds.valid_id
+        out[f"hp_{tag}_actions"] = np.array([it["action"] for it in ds.gt_dataset])
+        out[f"hp_{tag}_image_path"] = np.array([str(s) for s in ds.image_path])
+    # eval_multi on the valid, every-2nd subset: best-of-H action-wise error + the printed PCK / AUC
+    ds = MPII3DHP(os.path.join(ASSETS, "3dhp"), "test", gt2d=True, abs_coord=True, sample_interval=2, flip=False)
+    N, H = len(ds.db_3d), 4
+    g = np.random.Generator(np.random.Philox(key=[91, 5]))
+    rel = ds.db_3d - ds.db_3d[:, 0:1]
+    preds = (rel[:, None] + 0.06 * g.standard_normal((N, H, 17, 3))).astype(np.float32)
+    out["hp_preds"] = preds
+    for proto in (False, True):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            err = ds.eval_multi(preds.copy(), protocol2=proto)
+        txt = buf.getvalue()
+        k = "p2" if proto else "p1"
+        assert np.isfinite(err), "an action of the table has no sample"
+        out[f"hp_{k}"] = np.float64(err)
+        out[f"hp_{k}_pck"] = np.float64(re.search(r"PCK : ([0-9.eE+-]+)", txt).group(1))
+        out[f"hp_{k}_auc"] = np.float64(re.search(r"AUC : ([0-9.eE+-]+)", txt).group(1))
+    # PCK / AUC helpers directly
+    a = (0.08 * g.standard_normal((30, 17, 3))).astype(np.float32)
+    b = (a + 0.07 * g.standard_normal((30, 17, 3))).astype(np.float32)
+    out["pck_gts"], out["pck_preds"] = a, b
+    out["pck_150"] = np.float64(mutils.compute_PCK(a, b))
+    out["pck_50_joints"] = np.float64(mutils.compute_PCK(a, b, eval_joints=[1, 2, 3, 14, 15, 16], threshold=50))
+    out["auc"] = np.float64(mutils.compute_AUC(a, b))
+    out["auc_joints"] = np.float64(mutils.compute_AUC(a, b, eval_joints=[0, 7, 8, 9, 10]))
+    # SkiPose eval_multi (reader needs h5py + the real asset)
+    sk = object.__new__(skiPose)
+    sk.db_3d = (ds.db_3d + 0.5).astype(np.float32)
+    out["ski_db_3d"] = sk.db_3d
+    out["ski_p1"] = np.float64(sk.eval_multi(preds, protocol2=False))
+    out["ski_p2"] = np.float64(sk.eval_multi(preds, protocol2=True))
+    save("hp3d_ski", **out)
+
+
 GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo, oil=gen_oil,
             eval=gen_eval, driver=gen_driver, datasets=gen_datasets,
-            driver_files=gen_driver_files, samplers=gen_samplers, pc_generic=gen_pc_generic)
+            driver_files=gen_driver_files, samplers=gen_samplers, pc_generic=gen_pc_generic, hp3d_ski=gen_3dhp_ski)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

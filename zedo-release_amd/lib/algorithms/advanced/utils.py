@@ -4,6 +4,7 @@ Only what the sampling path uses is here: `quaternion_to_matrix` (:59-88), `get_
 `get_score_fn` (:736-800) and the two flatten helpers (:803-810).  The vendored PyTorch3D rotation
 library, the model registry and the PCK/AUC helpers of the reference are not on the path.
 """
+import numpy as np
 import torch
 
 from . import sde_lib
@@ -62,3 +63,18 @@ def to_flattened_numpy(x):
 
 def from_flattened_numpy(x, shape):
     return torch.from_numpy(x.reshape(shape))
+
+
+def compute_PCK(gts, preds, scales=1000, eval_joints=None, threshold=150):
+    """Percentage of joints closer than `threshold` mm to the label (reference :814-838).  gts / preds [N,J,3] in
+    metres; `scales` is ignored exactly as in the reference (a fixed factor of 1000 converts to mm)."""
+    gts, preds = np.asarray(gts), np.asarray(preds)
+    joints = list(range(gts.shape[1])) if eval_joints is None else eval_joints
+    err = np.sqrt(np.sum(np.power(preds - gts, 2), axis=2)) * 1000          # [N, J], dtype of the inputs
+    err = np.take(err, joints, axis=1)
+    return float((err < threshold).sum() / err.size) * 100
+
+
+def compute_AUC(gts, preds, scales=1000, eval_joints=None):
+    """Mean PCK over the thresholds 0, 5, ..., 150 mm of `mpii_compute_3d_pck.m` (reference :841-849)."""
+    return np.mean([compute_PCK(gts, preds, scales, eval_joints, th) for th in np.linspace(0, 150, 31)])

@@ -57,6 +57,13 @@ def make_dataset(config, args, inference):
         if ds == "h36m":
             act = 2 + (np.arange(args.synthetic) % 15)
             return H36MDataset3D.from_arrays(d["db_2d"], d["db_3d"].astype(np.float64) * 1000.0, d["camera_param"], act)
+        if ds == "3dhp":
+            from lib.dataset.mpii3dHP import ACTIONS, MPII3DHP
+            act = np.array(ACTIONS)[np.arange(args.synthetic) % len(ACTIONS)]
+            return MPII3DHP.from_arrays(d["db_2d"], d["db_3d"].astype(np.float64) * 1000.0, d["camera_param"], act)
+        if ds == "ski":
+            from lib.dataset.skiPose import skiPose
+            return skiPose.from_arrays(d["db_2d"], d["db_3d"], d["camera_param"])
         return PW3D.from_arrays(d["db_2d"], d["db_3d"], d["camera_param"])
     if ds == "h36m":
         from lib.dataset.h36m import H36MDataset3D
@@ -66,12 +73,20 @@ def make_dataset(config, args, inference):
         from lib.dataset.pw3d import PW3D
         return PW3D(Path("data", "3dpw"), "test", gt2d=args.gt, abs_coord=True, sample_interval=config.ZeDO.sample,
                     flip=False)
+    if ds == "3dhp":
+        from lib.dataset.mpii3dHP import MPII3DHP
+        return MPII3DHP(Path("data", "3dhp"), "test", gt2d=args.gt, abs_coord=True, sample_interval=config.ZeDO.sample,
+                        flip=False)
+    if ds == "ski":
+        from lib.dataset.skiPose import skiPose
+        return skiPose(Path("data", "ski"), "test", gt2d=args.gt, abs_coord=True, sample_interval=config.ZeDO.sample,
+                       flip=False)
     if ds == "wild" and inference:
         from lib.dataset.custom import CustomDataset
         if not args.data:
             raise SystemExit("--data <file.npz> is required for the 'wild' dataset")
         return CustomDataset.from_npz(args.data)
-    raise NotImplementedError(f"dataset '{ds}' is outside the ported path (SURVEY.md 2, rows 12-13)")
+    raise NotImplementedError(f"dataset '{ds}' is outside the ported path (SURVEY.md 2, rows 14-15: infant pipeline)")
 
 
 def run(args, inference=False):
