@@ -6,6 +6,8 @@
 #include <chrono>
 #include <vector>
 #include <random>
+#include <string>
+#include <cstring>
 
 using namespace zedo;
 
@@ -111,6 +113,7 @@ int main(int argc, char **argv) {
     }
     std::vector<float> y((size_t)M * N);
     for (int var = 0; var < UBENCH_NVAR; ++var) {
+        if (getenv("UBENCH_ONLY") && !strstr(getenv("UBENCH_ONLY"), ("," + std::to_string(var) + ",").c_str())) continue;
         CK(hipMemset(dy, 0xff, (size_t)M * N * 4));
         hipError_t e = launch_variant(a, var, 0);
         if (e != hipSuccess) { printf("variant %d: launch error %s\n", var, hipGetErrorString(e)); continue; }
@@ -123,7 +126,7 @@ int main(int argc, char **argv) {
             if (!(d <= 1e-4)) { if (badrow < 0) badrow = rows[ri]; ++nbad; }
             if (!(d <= maxd)) maxd = d;
         }
-        const int reps = 100;
+        const int reps = getenv("UBENCH_REPS") ? atoi(getenv("UBENCH_REPS")) : 100;
         for (int r = 0; r < 250; ++r) launch_variant(a, var, 0);   // clocks ramp up over ~100 ms: warm up first
         CK(hipEventRecord(e0));
         for (int r = 0; r < reps; ++r) launch_variant(a, var, 0);

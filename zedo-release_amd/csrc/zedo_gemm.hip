@@ -43,6 +43,7 @@ namespace zedo {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 
 // global -> LDS DMA of 64 x 16 bytes: source = wave-uniform 64-bit base + per-lane 32-bit byte offset, destination =
@@ -69,11 +70,53 @@ __device__ __forceinline__ float silu_fast(float y) {
 template <int EPI>
 __device__ __forceinline__ void epilogue_values(const f32x16 &acc, const f32x4 (&b4)[4], const f32x4 (&ga)[4],
                                                 const f32x4 (&be)[4], float sde_c, float (&o)[16]) {
+    if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
+        // Same arithmetic as the scalar form below, written on float pairs so that it maps to v_pk_add / v_pk_mul /
+        // v_pk_fma_f32 (two results per VALU issue slot): VALU issue time is matrix-pipe time for the co-resident
+        // workgroup, and this epilogue is the largest non-MFMA item of the layer.
+        f32x2 p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x2 a2 = {acc[2 * k], acc[2 * k + 1]};
+            const f32x2 b2 = {b4[k >> 1][2 * (k & 1)], b4[k >> 1][2 * (k & 1) + 1]};
+            p[k] = a2 + b2;
+        }
+        f32x2 s2 = p[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s2 += p[k];
+        float s = s2.x + s2.y;
+        s += __shfl_xor(s, 32);
+        const float mean = s * (1.0f / 32.0f);
+        const f32x2 m2 = {mean, mean};
+        f32x2 q2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            p[k] -= m2;
+            q2 = __builtin_elementwise_fma(p[k], p[k], q2);
+        }
+        float qs = q2.x + q2.y;
+        qs += __shfl_xor(qs, 32);
+        const float rstd = __builtin_amdgcn_rsqf(qs * (1.0f / 32.0f) + 1e-5f);
+        const f32x2 r2 = {rstd, rstd}, c2 = {-1.44269504088896340736f, -1.44269504088896340736f}, one2 = {1.0f, 1.0f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x2 g2 = {ga[k >> 1][2 * (k & 1)], ga[k >> 1][2 * (k & 1) + 1]};
+            const f32x2 e2 = {be[k >> 1][2 * (k & 1)], be[k >> 1][2 * (k & 1) + 1]};
+            const f32x2 y = __builtin_elementwise_fma(p[k], r2 * g2, e2);
+            const f32x2 t = y * c2;
+            const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + one2;
+            const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+            const f32x2 v = y * r;
+            o[2 * k] = v.x;
+            o[2 * k + 1] = v.y;
+        }
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[4 * g + e] = acc[4 * g + e] + b4[g][e];
-    if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
+    if constexpr (EPI == 99) {     // scalar statement of the GroupNorm + SiLU epilogue (kept as documentation of the packed form above)
         // GroupNorm(32 groups of 32 channels), biased variance, eps 1e-5 (model.py:116,145,150), then SiLU
         float s = 0.0f;
 #pragma unroll
@@ -112,7 +155,11 @@ __device__ long long *g_timeline = nullptr;   // ubench only: 8 x int64 per work
 // tiles, whose iterations are shorter than the DMA latency).  NODMA = 1 (ubench ablation only).
 // BK = K depth of one LDS tile: 32 (128-byte rows) or 16 (64-byte rows: half the LDS, so that three 128x128
 // workgroups fit on a CU).
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32>
+// SCHED (instruction placement inside the K loop): bit 0 = pin every fragment read in front of the MFMA group
+// that hides it (the compiler otherwise sinks the ds_reads to their first use and exposes the LDS latency);
+// bit 1 = issue the DMA of a tile one instruction at a time between the MFMAs of the two groups that follow the
+// barrier instead of as one burst right behind it.
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0>
 __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, const int nwg) {
     constexpr int NW = WM * WN;
     constexpr int CPR = BK / 4;                         // 16-byte chunks per tile row (8 or 4)
@@ -156,15 +203,17 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
     const unsigned wlane = (unsigned)(drow * a.ldw + (dpos ^ dswz) * 4) * 4u;
     const unsigned xlane = (unsigned)(drow * a.ldx + (dpos ^ dswz) * 4) * 4u;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)smem;   // LDS byte address of As
+    auto dma_one = [&](int kt, int buf, int p) {       // instruction p (compile-time after unrolling) of a tile: W rows first, then X rows
+        if (p < IA)
+            dma16(Wbase + (size_t)kt * (BK * 4) + (size_t)p * (RPD * 4) * a.ldw, wlane,
+                  lds0 + (unsigned)(((buf * BN + (wid * IA + p) * RPD) * BK) * 4));
+        else
+            dma16(Xbase + (size_t)kt * (BK * 4) + (size_t)(p - IA) * (RPD * 4) * a.ldx, xlane,
+                  lds0 + (unsigned)(((NBUF * BN + buf * BM + (wid * IB + (p - IA)) * RPD) * BK) * 4));
+    };
     auto dma = [&](int kt, int buf) {
-        const char *wk = Wbase + (size_t)kt * (BK * 4);
-        const char *xk = Xbase + (size_t)kt * (BK * 4);
 #pragma unroll
-        for (int p = 0; p < IA; ++p)
-            dma16(wk + (size_t)p * (RPD * 4) * a.ldw, wlane, lds0 + (unsigned)(((buf * BN + (wid * IA + p) * RPD) * BK) * 4));
-#pragma unroll
-        for (int p = 0; p < IB; ++p)
-            dma16(xk + (size_t)p * (RPD * 4) * a.ldx, xlane, lds0 + (unsigned)(((NBUF * BN + buf * BM + (wid * IB + p) * RPD) * BK) * 4));
+        for (int p = 0; p < IPW; ++p) dma_one(kt, buf, p);
     };
 
     // ---- fragment reads: k-chunk c = 2*kg + kh of row i lives at position c ^ swz(i); tile bases are
@@ -175,7 +224,7 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
     for (int kg = 0; kg < KG; ++kg) foff[kg] = ((2 * kg + kh) ^ fswz) * 4;
     const float *Ab0 = As + (wn * TN + li) * BK;
     const float *Bb0 = Bs + (wm * TM + li) * BK;
-    f32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
+    f32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ], fa2[TI], fb2[TJ], fa3[TI], fb3[TJ];   // sets 2, 3: SCHED & 8 only
     auto fread = [&](f32x4(&fa)[TI], f32x4(&fb)[TJ], int buf, int kg) {
 #pragma unroll
         for (int i = 0; i < TI; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(Ab0 + (buf * BN + i * 32) * BK + foff[kg]);
@@ -198,6 +247,26 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     };
+    // one MFMA group with DMA instructions [p0, p0 + cnt) of tile `kt` (ring slot `buf`) spread between its four sub-groups
+    constexpr int H1 = (IPW + 1) / 2, H2 = IPW - H1;      // issued behind the barrier / in the first group of the next iteration
+    auto mma_dma = [&](const f32x4(&fa)[TI], const f32x4(&fb)[TJ], int kt, int buf, int p0, int cnt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < cnt && q * 4 / cnt == e) {         // cnt <= 4: DMA q goes in front of sub-group q*4/cnt
+                    dma_one(kt, buf, p0 + q);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    static_assert(!(SCHED & 2) || (H1 <= 4 && !(NODMA & 1)), "spread DMA: at most 4 instructions per MFMA group");
 
     //   iteration kt (tile kt in ring slot kt % NBUF; F0 = fragments (kt, kg 0) already in registers):
     //       F1 = read(kt,1); MFMA(F0);  F0 = read(kt,2); MFMA(F1);  F1 = read(kt,3); MFMA(F0)
@@ -228,28 +297,73 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
       for (int buf = 0; buf < NBUF; ++buf) {
         const int kt = kt0 + buf;
         const int nxt = (buf + 1 == NBUF) ? 0 : buf + 1;
+        const int prv = (buf == 0) ? NBUF - 1 : buf - 1;
+        if constexpr ((SCHED & 8) != 0) {
+            // four fragment sets: every read of tile kt is issued one MFMA group before the barrier, so the barrier
+            // waits for nothing and is followed by two groups whose operands are already in registers
+            static_assert(!(SCHED & 8) || KG == 4, "SCHED 8 needs BK = 32");
+            fread(fa1, fb1, buf, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            fread(fa2, fb2, buf, 2);
+            fread(fa3, fb3, buf, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
+            __syncthreads();
+            fread(fa0, fb0, nxt, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_dma(fa2, fb2, min(kt + NBUF, KT - 1), buf, 0, H1);
+            mma_dma(fa3, fb3, min(kt + NBUF, KT - 1), buf, H1, H2);
+            continue;
+        }
         fread(fa1, fb1, buf, 1);
-        mma(fa0, fb0);
+        if constexpr (SCHED & 1) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SCHED & 2) mma_dma(fa0, fb0, min(kt - 1 + NBUF, KT - 1), prv, H1, H2);   // second half of the tile begun behind the last barrier
+        else mma(fa0, fb0);
         if constexpr (KG == 4) {
             fread(fa0, fb0, buf, 2);
+            if constexpr (SCHED & 1) __builtin_amdgcn_sched_barrier(0);
             mma(fa1, fb1);
+            if constexpr (SCHED & 1) __builtin_amdgcn_sched_barrier(0);
             fread(fa1, fb1, buf, 3);
+            if constexpr (SCHED & 1) __builtin_amdgcn_sched_barrier(0);
             mma(fa0, fb0);
         }
+        if constexpr (SCHED & 4) __builtin_amdgcn_sched_barrier(0);   // keep the barrier behind the whole MFMA group
         // hipcc (ROCm 7.2) emits only lgkmcnt(0) before this barrier: it does not count the outstanding LDS-DMA,
         // so wait explicitly until tile kt+1 has landed (the NBUF-2 younger tiles may stay in flight).
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
         __syncthreads();
         // Branch-free on purpose (one basic block, so these issue under the MFMAs below): past the last
         // tile the DMA refills a buffer nobody reads again and the fragment read fetches unused values.
-        if (!NODMA) dma(min(kt + NBUF, KT - 1), buf);
-        fread(fa0, fb0, nxt, 0);
-        mma(fa1, fb1);
+        if constexpr (SCHED & 2) {
+            fread(fa0, fb0, nxt, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_dma(fa1, fb1, min(kt + NBUF, KT - 1), buf, 0, H1);
+        } else {
+            if (!(NODMA & 1)) dma(min(kt + NBUF, KT - 1), buf);
+            fread(fa0, fb0, nxt, 0);
+            if constexpr (SCHED & 1) __builtin_amdgcn_sched_barrier(0);
+            mma(fa1, fb1);
+            if constexpr (SCHED & 1) __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // drain the trailing (unused) DMA before any wave of the workgroup may exit
     TL_MARK(tl2)
+    if constexpr (NODMA >= 2) {   // ubench ablation: no epilogue (keep the accumulators alive)
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) keep += acc[i][j][0] + acc[i][j][15];
+        if (keep == 12345.678f) a.out[0] = keep;
+        return;
+    }
 
     // ---------------- epilogue: all global traffic goes through the (now free) LDS as 1 KB wave accesses ----
     // Direct stores from the accumulator layout would be 16 bytes per lane at a 4 KB row stride: 4x the VMEM
@@ -341,42 +455,69 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32>
-__global__ __launch_bounds__(WM *WN * 64) void layer_kernel(LayerArgs a) {
-    layer_body<BM, BN, WM, WN, EPI, NBUF, NODMA, BK>(a, blockIdx.x, gridDim.x);
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1>
+__global__ __launch_bounds__(WM *WN * 64, WPE) void layer_kernel(LayerArgs a) {
+    layer_body<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED>(a, blockIdx.x, gridDim.x);
 }
 
 // One launch, two tile shapes: workgroups [0, nbig) run 128x128 tiles on the rows that fill whole rounds of the
 // chip, workgroups [nbig, grid) run 32x128 tiles on the remainder rows.  Workgroups are dispatched in order, so the
 // small tiles start as CUs run out of big tiles and fill the tail of the launch instead of costing a separate,
 // latency-bound launch (40 us -> ~15 us per layer at 50 750 rows).  Both shapes use 256 threads.
-template <int EPI>
-__global__ __launch_bounds__(256) void layer_pair_kernel(LayerArgs big, LayerArgs small, int nbig) {
-    if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 2, EPI, 2, 0, 32>(big, blockIdx.x, nbig);
-    else layer_body<32, 128, 1, 4, EPI, 2, 0, 32>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+#ifndef ZEDO_SCHED_BIG
+#define ZEDO_SCHED_BIG 3
+#endif
+#ifndef ZEDO_SCHED_SMALL
+#define ZEDO_SCHED_SMALL 0
+#endif
+#ifndef ZEDO_SCHED_THIN
+#define ZEDO_SCHED_THIN 3
+#endif
+constexpr int SCHED_BIG = ZEDO_SCHED_BIG, SCHED_SMALL = ZEDO_SCHED_SMALL, SCHED_THIN = ZEDO_SCHED_THIN;
+
+// W8 = 0: 4 waves per workgroup (64x64 per wave; remainder in 32x128 tiles); W8 = 1: 8 waves (64x32 per wave, 82
+// registers, four waves per SIMD; remainder in 64x128 tiles) - measured faster for the residual epilogue, whose
+// residual DMA + wait has more co-resident waves to hide behind.
+#ifndef ZEDO_PAIR_W8_PLAIN
+#define ZEDO_PAIR_W8_PLAIN 0
+#endif
+#ifndef ZEDO_PAIR_W8_RES
+#define ZEDO_PAIR_W8_RES 1
+#endif
+template <int EPI, int W8>
+__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 1) void layer_pair_kernel(LayerArgs big, LayerArgs small, int nbig) {
+    if constexpr (W8) {
+        if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 4, EPI, 2, 0, 32, SCHED_BIG>(big, blockIdx.x, nbig);
+        else layer_body<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+    } else {
+        if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 2, EPI, 2, 0, 32, SCHED_BIG>(big, blockIdx.x, nbig);
+        else layer_body<32, 128, 1, 4, EPI, 2, 0, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+    }
 }
 
 template <int EPI>
 static hipError_t launch_pair(const LayerArgs &big, const LayerArgs &small, hipStream_t st) {
+    constexpr int W8 = (EPI == EPI_GN_SILU_RES) ? ZEDO_PAIR_W8_RES : ZEDO_PAIR_W8_PLAIN;
+    constexpr int SM = W8 ? 64 : 32;                                                    // remainder tile rows
     constexpr size_t lds = ((size_t)2 * (128 + 128) * 32 + 3 * 128) * sizeof(float);   // the big shape's need covers the small one's
-    if (big.Mp % 128 || small.Mp % 32 || big.N % 128 || big.K % 64) return hipErrorInvalidValue;
-    auto kern = layer_pair_kernel<EPI>;
+    if (big.Mp % 128 || small.Mp % SM || big.N % 128 || big.K % 64) return hipErrorInvalidValue;
+    auto kern = layer_pair_kernel<EPI, W8>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    const int nbig = (big.Mp / 128) * (big.N / 128), nsmall = (small.Mp / 32) * (small.N / 128);
-    hipLaunchKernelGGL(kern, dim3(nbig + nsmall), dim3(256), lds, st, big, small, nbig);
+    const int nbig = (big.Mp / 128) * (big.N / 128), nsmall = (small.Mp / SM) * (small.N / 128);
+    hipLaunchKernelGGL(kern, dim3(nbig + nsmall), dim3(W8 ? 512 : 256), lds, st, big, small, nbig);
     return hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32>
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1>
 static hipError_t launch_cfg(const LayerArgs &a, hipStream_t st) {
     constexpr size_t lds = ((size_t)NBUF * (BM + BN) * BK + 3 * BN) * sizeof(float);
     if (a.Mp <= 0 || a.Mp % BM || a.N % BN || a.K % (BK * NBUF)) return hipErrorInvalidValue;
-    auto kern = layer_kernel<BM, BN, WM, WN, EPI, NBUF, NODMA, BK>;
+    auto kern = layer_kernel<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, WPE>;
     static bool attr_done = false;  // per instantiation; benign race (idempotent call)
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -412,9 +553,9 @@ static LayerArgs rows_of(const LayerArgs &a, int row0, int rows) {
 // to spread over more CUs.
 template <int EPI>
 static hipError_t launch_small(const LayerArgs &a, hipStream_t st) {
-    if (a.Mp <= 2048 && a.Mp % 32 == 0) return launch_cfg<32, 128, 1, 4, EPI, 4>(a, st);
-    if (a.Mp <= 8192) return launch_cfg<64, 128, 2, 4, EPI, 4>(a, st);    // few workgroups: hide the DMA latency in the ring
-    return launch_cfg<64, 128, 2, 4, EPI, 2>(a, st);                      // many: three co-resident workgroups hide it
+    if (a.Mp <= 2048 && a.Mp % 32 == 0) return launch_cfg<32, 128, 1, 4, EPI, 4, 0, 32, SCHED_THIN & 1>(a, st);
+    if (a.Mp <= 8192) return launch_cfg<64, 128, 2, 4, EPI, 4, 0, 32, SCHED_THIN>(a, st);    // few workgroups: hide the DMA latency in the ring
+    return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);                      // many: three co-resident workgroups hide it
 }
 
 // N == 1024 or 512 (hidden / embedding width): 128x128 tiles (4 waves, two workgroups per CU so that one
@@ -427,7 +568,7 @@ static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
     // K <= 64 (pre_dense): almost no MFMA work per output, the layer is bound by writing the activation:
     // many small co-resident workgroups overlap their stores, one big tile per CU cannot.
     // (measured at 50 750 rows: 64x128 82 us; 32x128 92 us; 128x128 91 us; 64x256 108 us)
-    if (a.K <= 64) return launch_cfg<64, 128, 2, 4, EPI, 2>(a, st);
+    if (a.K <= 64) return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);
     const int per_round = num_cus() * 2 * 128 / (a.N / 128);      // rows covered by one full round of 128x128 tiles, 2 per CU
     const int rows_big = (a.Mp / per_round) * per_round;
     const int rows_small = a.Mp - rows_big;                       // multiple of 256 (ROW_PAD)
@@ -436,7 +577,7 @@ static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
         return launch_pair<EPI>(rows_of(a, 0, rows_big), rows_of(a, rows_big, rows_small), st);
     hipError_t e = hipSuccess;
     if (rows_small > 0) e = launch_small<EPI>(rows_of(a, rows_big, rows_small), st);
-    if (e == hipSuccess && rows_big > 0) e = launch_cfg<128, 128, 2, 2, EPI>(rows_of(a, 0, rows_big), st);
+    if (e == hipSuccess && rows_big > 0) e = launch_cfg<128, 128, 2, 2, EPI, 2, 0, 32, SCHED_BIG>(rows_of(a, 0, rows_big), st);
     return e;
 }
 
@@ -446,8 +587,8 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
         // (measured 70.6 us vs 75.7 us for 128-row tiles and 88 us for 32-row tiles at 50 750 rows)
         const bool small = a.Mp <= 8192 && a.Mp % 32 == 0;
         switch (epilogue) {
-            case EPI_SDE: return small ? launch_cfg<32, 64, 1, 2, EPI_SDE, 4>(a, st) : launch_cfg<64, 64, 2, 2, EPI_SDE, 4>(a, st);
-            case EPI_BIAS: return small ? launch_cfg<32, 64, 1, 2, EPI_BIAS, 4>(a, st) : launch_cfg<64, 64, 2, 2, EPI_BIAS, 4>(a, st);
+            case EPI_SDE: return small ? launch_cfg<32, 64, 1, 2, EPI_SDE, 4, 0, 32, SCHED_THIN>(a, st) : launch_cfg<64, 64, 2, 2, EPI_SDE, 4, 0, 32, SCHED_THIN>(a, st);
+            case EPI_BIAS: return small ? launch_cfg<32, 64, 1, 2, EPI_BIAS, 4, 0, 32, SCHED_THIN>(a, st) : launch_cfg<64, 64, 2, 2, EPI_BIAS, 4, 0, 32, SCHED_THIN>(a, st);
         }
         return hipErrorInvalidValue;
     }
@@ -463,7 +604,7 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
 
 #ifdef ZEDO_UBENCH
 // ---- variant table for tools/ubench/ubench_gemm.hip ----
-constexpr int UBENCH_NVAR = 17;
+constexpr int UBENCH_NVAR = 40;
 static const char *variant_name(int v) {
     switch (v) {
         case 0: return "product launch_layer (128x128 x2/CU + 32x128 remainder, one launch)";
@@ -483,6 +624,29 @@ static const char *variant_name(int v) {
         case 14: return "128x128 4 waves, BK16 ring 2, GN_SILU_RES";
         case 15: return "256x128 4 waves, BK16 ring 2, GN_SILU_RES";
         case 16: return "256x128 4 waves (128x64 each), BK16 ring 4";
+        case 17: return "128x128 BK32 ring 2, reads pinned (SCHED 1)";
+        case 18: return "128x128 BK32 ring 2, DMA spread (SCHED 2)";
+        case 19: return "128x128 BK32 ring 2, pinned + spread (SCHED 3)";
+        case 20: return "128x128 BK16 ring 4, reads pinned (SCHED 1)";
+        case 21: return "128x128 BK16 ring 4, pinned + spread (SCHED 3)";
+        case 22: return "128x128 BK32 ring 2, SCHED 3, GN_SILU_RES";
+        case 23: return "128x128 BK32 ring 2, SCHED 7 (barrier behind the MFMA group)";
+        case 24: return "128x128 BK32 ring 2, SCHED 7, GN_SILU_RES";
+        case 25: return "128x128 BK32 ring 2, SCHED 11 (4 fragment sets, barrier mid-stream)";
+        case 26: return "128x128 BK32 ring 2, SCHED 11, GN_SILU_RES";
+        case 27: return "128x128 SCHED 1, no in-loop DMA [ablation]";
+        case 28: return "128x128 SCHED 3, no epilogue [ablation]";
+        case 29: return "128x128 SCHED 1, no in-loop DMA, no epilogue [ablation]";
+        case 30: return "128x128 BK16 ring 2, SCHED 1, 3 waves/SIMD (3 WG/CU)";
+        case 31: return "128x128 BK16 ring 2, SCHED 1, 3 waves/SIMD, GN_SILU_RES";
+        case 32: return "128x128 BK16 ring 2, SCHED 0, 3 waves/SIMD";
+        case 33: return "128x128 BK16 ring 2, SCHED 1 (2 waves/SIMD by registers)";
+        case 34: return "128x128 8 waves (2x4: 64x32 per wave), SCHED 3, 4 waves/SIMD";
+        case 35: return "128x128 8 waves (4x2: 32x64 per wave), SCHED 3, 4 waves/SIMD";
+        case 36: return "128x128 8 waves (2x4), SCHED 3, 4 waves/SIMD, GN_SILU_RES";
+        case 37: return "256x256 8 waves (2x4), SCHED 3";
+        case 38: return "256x256 8 waves (2x4), SCHED 3, GN_SILU_RES";
+        case 39: return "128x128 8 waves (2x4), SCHED 1, 4 waves/SIMD";
     }
     return "?";
 }
@@ -505,6 +669,29 @@ static hipError_t launch_variant(const LayerArgs &a, int v, hipStream_t st) {
         case 14: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 16>(a, st);
         case 15: return launch_cfg<256, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 16>(a, st);
         case 16: return launch_cfg<256, 128, 2, 2, EPI_GN_SILU, 4, 0, 16>(a, st);
+        case 17: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 1>(a, st);
+        case 18: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 2>(a, st);
+        case 19: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 3>(a, st);
+        case 20: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 4, 0, 16, 1>(a, st);
+        case 21: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 4, 0, 16, 3>(a, st);
+        case 22: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 32, 3>(a, st);
+        case 23: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 7>(a, st);
+        case 24: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 32, 7>(a, st);
+        case 25: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 11>(a, st);
+        case 26: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 32, 11>(a, st);
+        case 27: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 1, 32, 1>(a, st);
+        case 28: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 2, 32, 3>(a, st);
+        case 29: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 3, 32, 1>(a, st);
+        case 30: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 16, 1, 3>(a, st);
+        case 31: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 16, 1, 3>(a, st);
+        case 32: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 16, 0, 3>(a, st);
+        case 33: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 16, 1>(a, st);
+        case 34: return launch_cfg<128, 128, 2, 4, EPI_GN_SILU, 2, 0, 32, 3, 4>(a, st);
+        case 35: return launch_cfg<128, 128, 4, 2, EPI_GN_SILU, 2, 0, 32, 3, 4>(a, st);
+        case 36: return launch_cfg<128, 128, 2, 4, EPI_GN_SILU_RES, 2, 0, 32, 3, 4>(a, st);
+        case 37: return launch_cfg<256, 256, 2, 4, EPI_GN_SILU, 2, 0, 32, 3>(a, st);
+        case 38: return launch_cfg<256, 256, 2, 4, EPI_GN_SILU_RES, 2, 0, 32, 3>(a, st);
+        case 39: return launch_cfg<128, 128, 2, 4, EPI_GN_SILU, 2, 0, 32, 1, 4>(a, st);
     }
     return hipErrorInvalidValue;
 }
