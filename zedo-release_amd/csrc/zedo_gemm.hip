@@ -24,17 +24,32 @@
 //     issuing VALU / global-load instructions is therefore lost to the matrix pipe: about 55 cycles
 //     per global_load_dwordx4 with its address add, 40 per ds_write_b128, 6-10 per VALU op.
 //   * Hence tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR destination, no
-//     ds_write pass), per-lane addresses are loop invariant (the K advance is a scalar add), tiles
-//     are as large as the register file allows (256x256 per 8-wave workgroup: 8 DMA instructions
-//     per wave per 128 MFMAs), and the GroupNorm/SiLU epilogue uses v_exp/v_rcp/v_rsq (<= 2 ulp).
+//     ds_write pass), per-lane addresses are loop invariant (scalar base advanced with scalar adds,
+//     issued from inline asm), and the GroupNorm/SiLU epilogue uses v_exp/v_rcp/v_rsq (<= 2 ulp) on
+//     float pairs (v_pk_add/mul/fma_f32).
 //   * LDS rows are unpadded 128-byte lines (the DMA destination is lane-linear by construction);
 //     bank conflicts are avoided by XOR-swizzling the 16-byte chunk index with (row & 7) on the
 //     SOURCE address and on the fragment read.
-//   * Software pipeline: fragments double-buffered in registers, ONE barrier per 32-wide K tile placed
-//     3/4 through the MFMA burst; tile kt+2 is DMA'd into the buffer of tile kt right after the
-//     barrier that proves every read of tile kt complete, so two LDS buffers suffice.
-//   * 256x256 tiles quantise badly on 256 CUs, so a layer is launched as: 64x128 tiles on the
-//     remainder rows first, then 256x256 tiles on the rows that fill whole rounds (launch_layer).
+//   * Software pipeline (SCHED template flag): fragments double-buffered in registers with every
+//     ds_read pinned (sched_barrier) in front of the MFMA group that hides it - left alone, hipcc
+//     sinks the reads to their first use, merges the two fragment sets and exposes the LDS latency
+//     16 times per K tile; ONE barrier per K tile; tile kt+2 is DMA'd into the buffer of tile kt
+//     behind the barrier that proves every read of tile kt complete (two LDS buffers suffice), one
+//     DMA instruction per four MFMAs over the next two groups instead of a burst: a burst of
+//     8 x 1 KB per wave queues on the CU's 64 B/clk vector-memory path and stalls the wave's MFMA issue.
+//   * Tile shape: 128x128 per workgroup, two workgroups per CU.  One workgroup alone runs its K loop
+//     at ~98 % of the pipe; what the second one buys is cover for prologue and epilogue.  Four waves
+//     (64x64 each) for the plain layers, eight waves (64x32 each, 82 registers, four per SIMD) for
+//     the residual layers, whose epilogue waits on a residual DMA.  Larger tiles (256x128, 256x256),
+//     BK = 16 rings with three or four workgroups per CU and four-fragment-set schedules are in the
+//     ubench variant table below; all measured equal or slower (profiles/ubench_gemm_*).
+//   * Tile quantisation: rows that do not fill a whole round of 2 workgroups x 256 CUs run as small
+//     tiles in the SAME launch (layer_pair_kernel): they back-fill CUs as the last big tiles drain.
+//   * Where the remaining ~8 % goes (ablations, profiles/ubench_gemm_49152_r01.txt): no epilogue
+//     -5.2 %, no in-loop DMA -1.7 %, neither: 150.8 TFLOP/s = 96.8 % of the measured MFMA peak.  The
+//     epilogue's ~550 VALU instructions per wave cannot issue under the partner's MFMAs, so it
+//     stretches from 4.6 us (alone) to ~27 us and a CU has both workgroups inside the K loop only
+//     ~45 % of the time (tools/ubench/timeline_stats.py).
 #include "zedo_internal.h"
 
 #include <cstdlib>
@@ -463,7 +478,7 @@ __global__ __launch_bounds__(WM *WN * 64, WPE) void layer_kernel(LayerArgs a) {
 // One launch, two tile shapes: workgroups [0, nbig) run 128x128 tiles on the rows that fill whole rounds of the
 // chip, workgroups [nbig, grid) run 32x128 tiles on the remainder rows.  Workgroups are dispatched in order, so the
 // small tiles start as CUs run out of big tiles and fill the tail of the launch instead of costing a separate,
-// latency-bound launch (40 us -> ~15 us per layer at 50 750 rows).  Both shapes use 256 threads.
+// latency-bound launch (40 us -> ~26 us per layer at 50 750 rows).  Both shapes of a launch use the same block size.
 #ifndef ZEDO_SCHED_BIG
 #define ZEDO_SCHED_BIG 3
 #endif
@@ -558,11 +573,9 @@ static hipError_t launch_small(const LayerArgs &a, hipStream_t st) {
     return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);                      // many: three co-resident workgroups hide it
 }
 
-// N == 1024 or 512 (hidden / embedding width): 128x128 tiles (4 waves, two workgroups per CU so that one
-// workgroup's prologue / epilogue hides under the other's MFMAs) on the rows that fill whole rounds of the chip,
-// small tiles (launched first, so that they pack in front) on the rest.  With the DMA addressing free of VALU
-// work this beats 256x256 tiles (one workgroup per CU, nothing hides its epilogue): 735 / 754 us vs 746 / 771 us
-// per plain / residual layer at 49152 rows.
+// N == 1024 or 512 (hidden / embedding width): 128x128 tiles, two workgroups per CU, on the rows that fill whole
+// rounds of the chip; the remainder rows as small tiles in the same launch (launch_pair).  716 / 729 us per plain /
+// residual layer at 49152 rows (144 / 141 TFLOP/s); 256x256 tiles (one workgroup per CU): 719 / 748 us.
 template <int EPI>
 static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
     // K <= 64 (pre_dense): almost no MFMA work per output, the layer is bound by writing the activation:
@@ -577,7 +590,10 @@ static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
         return launch_pair<EPI>(rows_of(a, 0, rows_big), rows_of(a, rows_big, rows_small), st);
     hipError_t e = hipSuccess;
     if (rows_small > 0) e = launch_small<EPI>(rows_of(a, rows_big, rows_small), st);
-    if (e == hipSuccess && rows_big > 0) e = launch_cfg<128, 128, 2, 2, EPI, 2, 0, 32, SCHED_BIG>(rows_of(a, 0, rows_big), st);
+    if (e == hipSuccess && rows_big > 0) {
+        if constexpr (EPI == EPI_GN_SILU_RES && ZEDO_PAIR_W8_RES) e = launch_cfg<128, 128, 2, 4, EPI, 2, 0, 32, SCHED_BIG, 4>(rows_of(a, 0, rows_big), st);
+        else e = launch_cfg<128, 128, 2, 2, EPI, 2, 0, 32, SCHED_BIG>(rows_of(a, 0, rows_big), st);
+    }
     return e;
 }
 
