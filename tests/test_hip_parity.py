@@ -276,6 +276,43 @@ def test_rows_are_independent_at_full_size(zh, W):
     assert g2.abs().max().item() < 1e-5 * max(1.0, x2.abs().max().item() + T.abs().max().item())
 
 
+def test_selection_properties_at_full_size(zh):
+    """BASELINE size (N = 1015, H = 50): the best-of-H selection must not depend on how the rows are sharded
+    (min over shards == global min, lowest index on ties) nor on the order of the hypotheses."""
+    from lib.dataset import synthetic as syn
+    H, N = 50, 1015
+    d = syn.make_poses(N, seed=5, dtype3d=np.float64)
+    gt = d["db_3d"] - d["db_3d"][:, 0:1]
+    rng = np.random.default_rng(3)
+    rows = (np.tile(gt, (H, 1, 1)) + 0.08 * rng.standard_normal((H * N, 17, 3))).astype(np.float32)
+    rows[7 * N:8 * N] = rows[3 * N:4 * N]                      # exact ties between hypotheses 3 and 7
+    x, g = dev(rows), dev(gt, torch.float64)
+    for p2 in (False, True):
+        err, best, idx = zh.min_mpjpe(x, g, N, procrustes=p2)
+        e = err.reshape(H, N)
+        assert torch.equal(best, e.min(0).values) and torch.equal(idx.long(), e.argmin(0))
+        assert not (idx == 7).any()                            # first minimum wins, like np.argmin
+        # three uneven shards, combined on the host the way reduce_min_over_ranks does
+        cuts = [0, 17 * N + 333, 31 * N + 1, H * N]
+        sb = torch.full((3, N), float("inf"), dtype=torch.float64, device="cuda")
+        si = torch.full((3, N), 2 ** 31 - 1, dtype=torch.int64, device="cuda")
+        for k in range(3):
+            lo, hi = cuts[k], cuts[k + 1]
+            _, b, i = zh.min_mpjpe(x[lo:hi].contiguous(), g, N, procrustes=p2, row_offset=lo)
+            sb[k] = b
+            si[k] = torch.where(i < 0, torch.full_like(i, 2 ** 31 - 1), i).long()
+        gb = sb.min(0).values
+        gi = torch.where(sb == gb, si, torch.full_like(si, 2 ** 31 - 1)).min(0).values
+        assert torch.equal(gb, best) and torch.equal(gi, idx.long())
+        # hypothesis order: reversing the hypotheses permutes the errors and nothing else
+        xr = x.reshape(H, N, 17, 3).flip(0).reshape(H * N, 17, 3).contiguous()
+        err_r, best_r, _ = zh.min_mpjpe(xr, g, N, procrustes=p2)
+        assert torch.equal(err_r.reshape(H, N).flip(0), e) and torch.equal(best_r, best)
+        if p2:      # the alignment minimises the SQUARED error; the mean joint distance drops for all but a few rows
+            assert err.mean() < err_p1.mean() and (err <= err_p1 + 1e-12).double().mean() > 0.99
+        err_p1 = err
+
+
 # ---------------------------------------------------------------- argument validation, chunking
 
 def test_bad_arguments_are_rejected(zh, W):
