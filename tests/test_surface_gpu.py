@@ -145,6 +145,32 @@ def test_fused_driver_config1_matches_reference(weights0, golden):
     assert abs(p2 - float(d["pa_mpjpe"])) < 5e-5, (p2, float(d["pa_mpjpe"]))
 
 
+def test_fused_driver_full_length_matches_reference(weights0, golden):
+    """The shipped loop length: S = 1000 OIL steps, H = 3 hypotheses, 3DPW settings (17-joint IPO, IPO_T 8), N = 160,
+    against the reference's own run on identical inputs and weights (tools/gen_golden.py::gen_driver_full)."""
+    import json
+    from zedo_hip.pipeline import Pipeline, ZeDOConfig
+    from lib.dataset.pw3d import PW3D
+    d = golden("driver_full")
+    pipe = Pipeline(weights0, ZeDOConfig.pw3d(), "cuda").load(d["clusters"], d["db_2d"], d["K"])
+    x, T = pipe.run()
+    ds = PW3D.from_arrays(d["db_2d"], d["db_3d"], d["K"])
+    p1 = ds.eval_multi(("rows", x), protocol2=False)
+    p2 = ds.eval_multi(("rows", x), protocol2=True)
+    ref = d["batch_results"]                                   # [N, H, 17, 3]
+    mine = x.reshape(3, 160, 17, 3).permute(1, 0, 2, 3).cpu().numpy()
+    dj = np.linalg.norm(mine - ref, axis=-1)                    # per-joint distance between the two final states
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_report.jsonl", "a") as f:
+        f.write(json.dumps({"test": "driver_full", "mpjpe_hip": p1, "mpjpe_ref": float(d["mpjpe"]), "pa_hip": p2,
+                            "pa_ref": float(d["pa_mpjpe"]), "joint_dist_median": float(np.median(dj)),
+                            "joint_dist_p99": float(np.percentile(dj, 99))}) + "\n")
+    print(f"driver_full: MPJPE {p1:.6f} vs {float(d['mpjpe']):.6f}, PA {p2:.6f} vs {float(d['pa_mpjpe']):.6f}, "
+          f"joint distance median {np.median(dj):.2e} p99 {np.percentile(dj, 99):.2e}")
+    assert abs(p1 - float(d["mpjpe"])) < 5e-5, (p1, float(d["mpjpe"]))
+    assert abs(p2 - float(d["pa_mpjpe"])) < 5e-5, (p2, float(d["pa_mpjpe"]))
+
+
 def test_run_opt_main_and_inference_synthetic(tmp_path):
     import run.inference as inf
     import run.opt_main as om

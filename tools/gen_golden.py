@@ -633,9 +633,34 @@ def gen_3dhp_ski():
     save("hp3d_ski", **out)
 
 
+
+def gen_driver_full():
+    """The full-length loop (S = 1000, H = 3) with the 3DPW settings of BASELINE configs[2] on N = 160 poses:
+    reference loop + PW3D.eval_multi.  ~2 minutes of CPU."""
+    w = syn.make_weights(seed=0)
+    m = ref_model(w)
+    N, H, S = 160, 3, 1000
+    d = syn.make_poses(N, seed=57, conf_mode="uniform")
+    cl = syn.make_clusters(H, seed=13)
+    gt_2d, K = d["db_2d"], d["camera_param"]
+    batch_results = []
+    for sid in range(H):
+        noisy = torch.ones_like(torch.tensor(d["db_3d"])) * torch.tensor(cl - cl[:, 0:1, :])[sid:sid + 1]
+        r = run_ref_ipo(noisy.numpy(), gt_2d[:, :, :2], K, "z", list(range(17)), 8.0, 0.2, 2.0, 500)
+        x = torch.tensor(r["R"]).bmm(noisy.permute(0, 2, 1)).permute(0, 2, 1).contiguous().numpy()
+        res, _, _ = run_ref_oil(m, x, gt_2d[:, :, :2], gt_2d[:, :, 2].copy(), K, r["T"], S, [])
+        batch_results.append(res)
+    batch_results = np.swapaxes(np.array(batch_results), 0, 1)
+    pw = _pw3d_obj(d["db_3d"])
+    p1 = pw.eval_multi(batch_results, protocol2=False)
+    p2 = pw.eval_multi(batch_results, protocol2=True)
+    save("driver_full", db_2d=gt_2d, db_3d=d["db_3d"], K=K, clusters=cl, mpjpe=np.float64(p1), pa_mpjpe=np.float64(p2),
+         batch_results=batch_results.astype(np.float32))
+
+
 GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo, oil=gen_oil,
             eval=gen_eval, driver=gen_driver, datasets=gen_datasets,
-            driver_files=gen_driver_files, samplers=gen_samplers, pc_generic=gen_pc_generic, hp3d_ski=gen_3dhp_ski)
+            driver_files=gen_driver_files, samplers=gen_samplers, pc_generic=gen_pc_generic, hp3d_ski=gen_3dhp_ski, driver_full=gen_driver_full)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
