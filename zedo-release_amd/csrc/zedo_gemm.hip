@@ -262,6 +262,7 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     };
+    double dummy0 = 1.0, dummy1 = 2.0;   // (NODMA & 4 ablation only)
     // one MFMA group with DMA instructions [p0, p0 + cnt) of tile `kt` (ring slot `buf`) spread between its four sub-groups
     constexpr int H1 = (IPW + 1) / 2, H2 = IPW - H1;      // issued behind the barrier / in the first group of the next iteration
     auto mma_dma = [&](const f32x4(&fa)[TI], const f32x4(&fb)[TJ], int kt, int buf, int p0, int cnt) {
@@ -278,6 +279,10 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+            if constexpr ((NODMA & 4) != 0) {   // ubench ablation: what does same-wave VALU cost next to the MFMAs?
+                asm volatile("v_pk_fma_f32 %0, %0, %0, %0\n\tv_pk_fma_f32 %1, %1, %1, %1\n\tv_pk_fma_f32 %0, %0, %0, %0\n\tv_pk_fma_f32 %1, %1, %1, %1"
+                             : "+v"(dummy0), "+v"(dummy1));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -370,8 +375,8 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // drain the trailing (unused) DMA before any wave of the workgroup may exit
     TL_MARK(tl2)
-    if constexpr (NODMA >= 2) {   // ubench ablation: no epilogue (keep the accumulators alive)
-        float keep = 0.f;
+    if constexpr ((NODMA & 2) != 0) {   // ubench ablation: no epilogue (keep the accumulators alive)
+        float keep = (float)(dummy0 + dummy1) * 0.f;
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -624,7 +629,7 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
 
 #ifdef ZEDO_UBENCH
 // ---- variant table for tools/ubench/ubench_gemm.hip ----
-constexpr int UBENCH_NVAR = 42;
+constexpr int UBENCH_NVAR = 45;
 static const char *variant_name(int v) {
     switch (v) {
         case 0: return "product launch_layer (128x128 x2/CU + 32x128 remainder, one launch)";
@@ -669,6 +674,9 @@ static const char *variant_name(int v) {
         case 39: return "128x128 8 waves (2x4), SCHED 1, 4 waves/SIMD";
         case 40: return "128x128 4 waves, SCHED 3, launch_bounds(256, 2)";
         case 41: return "128x128 4 waves, SCHED 3, launch_bounds(256, 2), GN_SILU_RES";
+        case 42: return "128x128 SCHED 3, lb(256,2), no epilogue, + 32 v_pk_fma per 64 MFMAs in the loop (1024 per tile) [ablation]";
+        case 43: return "128x128 SCHED 3, lb(256,2), with epilogue, + 32 v_pk_fma per 64 MFMAs in the loop [ablation]";
+        case 44: return "128x128 SCHED 3, lb(256,2), no epilogue [ablation]";
     }
     return "?";
 }
@@ -716,6 +724,9 @@ static hipError_t launch_variant(const LayerArgs &a, int v, hipStream_t st) {
         case 39: return launch_cfg<128, 128, 2, 4, EPI_GN_SILU, 2, 0, 32, 1, 4>(a, st);
         case 40: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 3, 2>(a, st);
         case 41: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 32, 3, 2>(a, st);
+        case 42: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 6, 32, 3, 2>(a, st);
+        case 43: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 4, 32, 3, 2>(a, st);
+        case 44: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 2, 32, 3, 2>(a, st);
     }
     return hipErrorInvalidValue;
 }
