@@ -7,39 +7,48 @@ The full interface is kept so that checkpoints round-trip.
 import torch
 
 
+def _trainable(parameters):
+    return [p for p in parameters if p.requires_grad]
+
+
 class ExponentialMovingAverage:
+    """shadow <- shadow - (1 - d) (shadow - p), with d = min(decay, (1 + n) / (10 + n)) while updates are counted."""
+
+    _FIELDS = ("decay", "num_updates", "shadow_params")
+
     def __init__(self, parameters, decay, use_num_updates=True):
-        if not 0.0 <= decay <= 1.0:
+        if decay < 0.0 or decay > 1.0:
             raise ValueError("Decay must be between 0 and 1")
-        self.decay = decay
-        self.num_updates = 0 if use_num_updates else None
-        self.shadow_params = [p.clone().detach() for p in parameters if p.requires_grad]
+        self.decay, self.num_updates = decay, (0 if use_num_updates else None)
+        self.shadow_params = [p.clone().detach() for p in _trainable(parameters)]
         self.collected_params = []
 
+    def _rate(self):
+        if self.num_updates is None:
+            return self.decay
+        self.num_updates += 1
+        return min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
+
+    @torch.no_grad()
     def update(self, parameters):
-        decay = self.decay
-        if self.num_updates is not None:
-            self.num_updates += 1
-            decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
-        with torch.no_grad():
-            for s, p in zip(self.shadow_params, [p for p in parameters if p.requires_grad]):
-                s.sub_((1.0 - decay) * (s - p))
+        keep = self._rate()
+        for shadow, p in zip(self.shadow_params, _trainable(parameters)):
+            shadow.sub_((1.0 - keep) * (shadow - p))
 
     def copy_to(self, parameters):
-        for s, p in zip(self.shadow_params, [p for p in parameters if p.requires_grad]):
-            p.data.copy_(s.data)
+        for shadow, p in zip(self.shadow_params, _trainable(parameters)):
+            p.data.copy_(shadow.data)
 
     def store(self, parameters):
         self.collected_params = [p.clone() for p in parameters]
 
     def restore(self, parameters):
-        for c, p in zip(self.collected_params, parameters):
-            p.data.copy_(c.data)
+        for saved, p in zip(self.collected_params, parameters):
+            p.data.copy_(saved.data)
 
     def state_dict(self):
-        return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)
+        return {k: getattr(self, k) for k in self._FIELDS}
 
     def load_state_dict(self, state_dict):
-        self.decay = state_dict["decay"]
-        self.num_updates = state_dict["num_updates"]
-        self.shadow_params = state_dict["shadow_params"]
+        for k in self._FIELDS:
+            setattr(self, k, state_dict[k])
