@@ -572,14 +572,27 @@ static LayerArgs rows_of(const LayerArgs &a, int row0, int rows) {
     return b;
 }
 
-// Small-tile launches (remainder rows, pre_dense, schedule tables, small batches): their K iterations are
-// shorter than the DMA latency, so they run on a 3- or 4-deep LDS ring; the smallest batches get 32-row tiles
-// to spread over more CUs.
+// Launches that do not fill the chip with 128x128 tiles (small and mid-size batches, schedule tables).  A CU's time
+// is ~6 us of prologue + epilogue plus the MFMA time of the tiles it ends up with, so what matters is how evenly the
+// tiles spread over the 256 CUs: finer tiles balance better, coarser tiles issue fewer DMAs per MFMA.  The choice
+// below minimises  rounds * 6 us + ceil(tiles / CUs) * tile_time  over the three shapes (model checked against
+// tools/ubench/ubench_gemm for 512..8192 rows: within 5 %); up to 256 tiles the 32-row shape on a 4-deep ring wins
+// on latency alone.
 template <int EPI>
 static hipError_t launch_small(const LayerArgs &a, hipStream_t st) {
-    if (a.Mp <= 2048 && a.Mp % 32 == 0) return launch_cfg<32, 128, 1, 4, EPI, 4, 0, 32, SCHED_THIN & 1>(a, st);
-    if (a.Mp <= 8192) return launch_cfg<64, 128, 2, 4, EPI, 4, 0, 32, SCHED_THIN>(a, st);    // few workgroups: hide the DMA latency in the ring
-    return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);                      // many: three co-resident workgroups hide it
+    const int ncol = a.N / 128, cus = num_cus();
+    if (a.Mp % 32 == 0 && (a.Mp / 32) * ncol <= cus) return launch_cfg<32, 128, 1, 4, EPI, 4, 0, 32, SCHED_THIN & 1>(a, st);
+    auto cost = [&](int bm, int slots_per_cu, double tile_us) {
+        if (a.Mp % bm) return 1e30;
+        const long tiles = (long)(a.Mp / bm) * ncol;
+        const long rounds = (tiles + (long)cus * slots_per_cu - 1) / ((long)cus * slots_per_cu);
+        return rounds * 6.0 + (double)((tiles + cus - 1) / cus) * tile_us;
+    };
+    const double kdepth = a.K / 1024.0;                               // tile times below are for K = 1024
+    const double c32 = cost(32, 3, 14.5 * kdepth), c64 = cost(64, 3, 28.2 * kdepth), c128 = cost(128, 2, 55.1 * kdepth);
+    if (c32 <= c64 && c32 <= c128) return launch_cfg<32, 128, 1, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);
+    if (c64 <= c128) return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);
+    return launch_cfg<128, 128, 2, 2, EPI, 2, 0, 32, SCHED_BIG, ZEDO_PLAIN_WPE>(a, st);
 }
 
 // N == 1024 or 512 (hidden / embedding width): 128x128 tiles, two workgroups per CU, on the rows that fill whole
@@ -629,7 +642,7 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
 
 #ifdef ZEDO_UBENCH
 // ---- variant table for tools/ubench/ubench_gemm.hip ----
-constexpr int UBENCH_NVAR = 45;
+constexpr int UBENCH_NVAR = 51;
 static const char *variant_name(int v) {
     switch (v) {
         case 0: return "product launch_layer (128x128 x2/CU + 32x128 remainder, one launch)";
@@ -677,6 +690,12 @@ static const char *variant_name(int v) {
         case 42: return "128x128 SCHED 3, lb(256,2), no epilogue, + 32 v_pk_fma per 64 MFMAs in the loop (1024 per tile) [ablation]";
         case 43: return "128x128 SCHED 3, lb(256,2), with epilogue, + 32 v_pk_fma per 64 MFMAs in the loop [ablation]";
         case 44: return "128x128 SCHED 3, lb(256,2), no epilogue [ablation]";
+        case 45: return "64x128 8 waves ring 2 SCHED 3 (3 WG/CU)";
+        case 46: return "64x128 8 waves ring 4 SCHED 3 (1 WG/CU)";
+        case 47: return "32x128 4 waves ring 4 SCHED 1 (1 WG/CU)";
+        case 48: return "32x128 4 waves ring 2 SCHED 3 (3 WG/CU)";
+        case 49: return "128x128 4 waves SCHED 3 lb(256,2)";
+        case 50: return "64x128 4 waves (2x2: 32x64 per wave) ring 2 SCHED 3";
     }
     return "?";
 }
@@ -727,6 +746,12 @@ static hipError_t launch_variant(const LayerArgs &a, int v, hipStream_t st) {
         case 42: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 6, 32, 3, 2>(a, st);
         case 43: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 4, 32, 3, 2>(a, st);
         case 44: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 2, 32, 3, 2>(a, st);
+        case 45: return launch_cfg<64, 128, 2, 4, EPI_GN_SILU, 2, 0, 32, 3>(a, st);
+        case 46: return launch_cfg<64, 128, 2, 4, EPI_GN_SILU, 4, 0, 32, 3>(a, st);
+        case 47: return launch_cfg<32, 128, 1, 4, EPI_GN_SILU, 4, 0, 32, 1>(a, st);
+        case 48: return launch_cfg<32, 128, 1, 4, EPI_GN_SILU, 2, 0, 32, 3>(a, st);
+        case 49: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 3, 2>(a, st);
+        case 50: return launch_cfg<64, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 3>(a, st);
     }
     return hipErrorInvalidValue;
 }
