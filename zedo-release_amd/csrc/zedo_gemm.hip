@@ -519,9 +519,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : ZEDO_PLAIN_WPE) void layer
     }
 }
 
-template <int EPI>
+template <int EPI, int W8>
 static hipError_t launch_pair(const LayerArgs &big, const LayerArgs &small, hipStream_t st) {
-    constexpr int W8 = (EPI == EPI_GN_SILU_RES) ? ZEDO_PAIR_W8_RES : ZEDO_PAIR_W8_PLAIN;
     constexpr int SM = W8 ? 64 : 32;                                                    // remainder tile rows
     constexpr size_t lds = ((size_t)2 * (128 + 128) * 32 + 3 * 128) * sizeof(float);   // the big shape's need covers the small one's
     if (big.Mp % 128 || small.Mp % SM || big.N % 128 || big.K % 64) return hipErrorInvalidValue;
@@ -608,8 +607,12 @@ static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
     const int rows_big = (a.Mp / per_round) * per_round;
     const int rows_small = a.Mp - rows_big;                       // multiple of 256 (ROW_PAD)
     static const bool split_launch = getenv("ZEDO_SPLIT_REMAINDER") != nullptr;   // A/B knob: remainder as its own launch
-    if (rows_small > 0 && rows_big > 0 && !split_launch)
-        return launch_pair<EPI>(rows_of(a, 0, rows_big), rows_of(a, rows_big, rows_small), st);
+    if (rows_small > 0 && rows_big > 0 && !split_launch) {
+        // eight-wave workgroups bring 64-row remainder tiles along; a short remainder finishes sooner as 32-row tiles
+        constexpr int W8 = (EPI == EPI_GN_SILU_RES) ? ZEDO_PAIR_W8_RES : ZEDO_PAIR_W8_PLAIN;
+        if (W8 && rows_small >= 1536) return launch_pair<EPI, W8>(rows_of(a, 0, rows_big), rows_of(a, rows_big, rows_small), st);
+        return launch_pair<EPI, 0>(rows_of(a, 0, rows_big), rows_of(a, rows_big, rows_small), st);
+    }
     hipError_t e = hipSuccess;
     if (rows_small > 0) e = launch_small<EPI>(rows_of(a, rows_big, rows_small), st);
     if (e == hipSuccess && rows_big > 0) {
