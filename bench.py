@@ -10,7 +10,8 @@ sharded contiguously over the ranks and the per-pose minimum is combined with on
 The JSON line also carries
   roofline     : the dominant kernel (the four 1024x1024 fp32-MFMA dense layers): algorithmic FLOP per launch
                  / its average launch duration, measured live with sampled HIP events on the launch stream;
-  cpu_baseline : the numpy oracle (a port of the reference) timed on the host cores on a bounded sample.
+  cpu_baseline : the CPU port under oracle/ (numpy IPO + torch-CPU-operator OIL steps on every host core, i.e. the
+                 operators the reference itself runs on a CPU) timed on a bounded sample.
 """
 import argparse
 import json
@@ -32,17 +33,18 @@ PEAK_FP32_MFMA_TFLOPS = 157.3                                        # MI355X_MI
 
 
 def cpu_baseline(weights, cfg_kw, seed):
-    """Oracle (numpy port of the reference path) on the host: IPO at the reference batch size + a bounded
-    number of OIL steps, extrapolated per pose-hypothesis.  Test infrastructure used only as a baseline."""
+    """CPU port of the reference path on the host cores: IPO at the reference batch size (numpy oracle) + a bounded
+    number of OIL steps with the multi-threaded port (torch CPU operators = what the reference runs on a CPU),
+    extrapolated per pose-hypothesis.  Test infrastructure used only as a baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import zedo_oracle as O
+    import zedo_oracle_mt as M
     from lib.dataset import synthetic as syn
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    n, steps = N_POSES, 16
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    n, steps = N_POSES, 30
     d = syn.make_poses(n, seed=seed)
     cl = syn.make_clusters(1, seed=seed)
     cond, K = d["db_2d"][:, :, :2], d["camera_param"]
@@ -52,24 +54,39 @@ def cpu_baseline(weights, cfg_kw, seed):
     T0 = O.ipo_init_T(cond, K, 8.0)
     R, T, _, _, _ = O.ipo_fit(x0[:, kl], T0, K, cond[:, kl], "z", 0.2, 2.0, 500)
     t_ipo = time.perf_counter() - t0
-    x = np.einsum("bij,bkj->bki", R, x0)
-    conf = O.clamp_conf(d["db_2d"][:, :, 2].copy())
+    port = M.StepPort(weights, cond, K, d["db_2d"][:, :, 2].copy())
+    x, Tt = torch.tensor(np.einsum("bij,bkj->bki", R, x0).astype(np.float32)), torch.tensor(T.astype(np.float32))
     ts = O.oil_timestamps(S_OIL)
+    # thread count: more is not faster for [1015 x 1024] operands (256 threads: 5.8 s per step on the GPU box);
+    # double from 8 while a step gets faster, keep the best
+    cores, best = 1, float("inf")
+    for th in [c for c in (8, 16, 32, 64, 128, 256) if c <= avail] or [avail]:
+        torch.set_num_threads(th)
+        port.step(x, Tt, ts[0], False)                  # warm the pool at this size
+        t0 = time.perf_counter()
+        for i in range(2):
+            port.step(x, Tt, ts[i], True)
+        dt = (time.perf_counter() - t0) / 2
+        if dt < best:
+            cores, best = th, dt
+        if dt > 1.5 * best:
+            break
+    torch.set_num_threads(cores)
+    port.step(x, Tt, ts[0], False)
     t0 = time.perf_counter()
-    for i in range(steps):   # half with the given T, half with the least-squares T, as in the real loop's mix
-        g, Tn = O.gradient_field_gen(cond, x, K, t=T if i < steps // 5 else None, conf=conf)
-        T = Tn
-        x = O.pc_step(weights, x + g, ts[i])
+    for i in range(steps):   # a fifth with the given T, the rest with the least-squares T, as in the real loop
+        x, Tt = port.step(x, Tt, ts[i], i >= steps // 5)
     t_step = (time.perf_counter() - t0) / steps
     gt = d["db_3d"] - d["db_3d"][:, 0:1]
     t0 = time.perf_counter()
-    O.hypothesis_errors(x[:, None], gt, False)
-    O.hypothesis_errors(x[:, None], gt, True)
+    O.hypothesis_errors(x.numpy()[:, None], gt, False)
+    O.hypothesis_errors(x.numpy()[:, None], gt, True)
     t_eval = time.perf_counter() - t0
     per_pose_hyp = (t_ipo + S_OIL * t_step + t_eval) / n
     return dict(value=1.0 / (N_HYPO * per_pose_hyp), unit="poses/s", cores=int(cores), kind="port",
-                sample=f"numpy oracle, {n} poses x 1 hypothesis: IPO 500 it ({t_ipo:.1f} s) + {steps} of {S_OIL} OIL "
-                       f"steps ({t_step * 1e3:.0f} ms/step) + P1/P2 metric, extrapolated to H={N_HYPO}, S={S_OIL}")
+                sample=f"CPU port (oracle/), {n} poses x 1 hypothesis: IPO 500 it, numpy ({t_ipo:.1f} s) + {steps} of {S_OIL} "
+                       f"OIL steps, torch CPU operators on {cores} of {avail} usable threads - the fastest count ({t_step * 1e3:.1f} ms/step) + P1/P2 metric, "
+                       f"extrapolated to H={N_HYPO}, S={S_OIL}")
 
 
 def main():

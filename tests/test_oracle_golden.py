@@ -145,3 +145,22 @@ def test_driver_config1_end_to_end(golden, weights0):
     gt = d["db_3d"] - d["db_3d"][:, 0:1]
     assert abs(O.eval_multi(res, gt)[0] - float(d["mpjpe"])) < 5e-5
     assert abs(O.eval_multi(res, gt, True)[0] - float(d["pa_mpjpe"])) < 5e-5
+
+
+def test_multithreaded_cpu_port_follows_the_oracle(weights0):
+    """oracle/zedo_oracle_mt.py (torch CPU operators, used by bench.py's cpu_baseline only) against the pinned numpy
+    oracle: one OIL iteration with the given T and with the least-squares T."""
+    import torch
+    import zedo_oracle_mt as M
+    d = syn.make_poses(12, seed=9, conf_mode="wild")
+    rng = np.random.default_rng(2)
+    x0 = (0.25 * rng.standard_normal((12, 17, 3))).astype(np.float32)
+    T0 = d["db_3d"][:, 0:1, :].astype(np.float32)
+    cond, K, conf = d["db_2d"][:, :, :2], d["camera_param"], d["db_2d"][:, :, 2].copy()
+    port = M.StepPort(weights0, cond, K, conf, threads=4)
+    for solve in (False, True):
+        g, Tn = O.gradient_field_gen(cond, x0, K, t=None if solve else T0, conf=conf.copy())
+        want = O.pc_step(weights0, x0 + g, 0.0555)
+        got, Tg = port.step(torch.tensor(x0), torch.tensor(T0), 0.0555, solve)
+        np.testing.assert_allclose(Tg.numpy(), Tn, atol=3e-5, rtol=0)
+        np.testing.assert_allclose(got.numpy(), want, atol=2e-5, rtol=0)
