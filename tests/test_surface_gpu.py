@@ -308,3 +308,54 @@ def test_opt_main_synthetic_3dhp_and_ski():
         a = om.parse_args(["prog", "--config", cfg_path(name), "--hypo", "2", "--synthetic", "28", "--oil_iterations", "10"])
         p1, p2 = om.main(a)
         assert np.isfinite(p1) and np.isfinite(p2) and p2 <= p1 + 1e-9
+
+
+def test_inference_from_files_in_the_wild(tmp_path, weights0, monkeypatch):
+    """run.inference on the 'wild' dataset fed from files: --data poses.npz (2D detections + intrinsics [+ labels]),
+    clusters/h36m_cluster{H}.npy, checkpoint .pth; results.npy holds every hypothesis [N, H, 17, 3] and --eval prints
+    the best-of-H metric.  The reference's own CustomDataset is a non-running template, so the
+    check is against the fused pipeline called directly on the same arrays."""
+    import run.inference as inf
+    from lib.algorithms.advanced.model import ScoreModelFC_Adv
+    from lib.algorithms.ema import ExponentialMovingAverage
+    from lib.dataset import synthetic as syn
+    from run._driver import load_config
+    from zedo_hip.pipeline import Pipeline, ZeDOConfig
+    N, H, S = 24, 3, 30
+    d = syn.make_poses(N, seed=12, conf_mode="uniform")
+    cl = syn.make_clusters(H, seed=4)
+    np.savez(tmp_path / "poses.npz", db_2d=d["db_2d"], camera_param=d["camera_param"], db_3d=d["db_3d"])
+    os.makedirs(tmp_path / "clusters")
+    np.save(tmp_path / "clusters" / f"h36m_cluster{H}.npy", cl)
+    cfg_file = tmp_path / "cfg_wild_small.py"
+    cfg_file.write_text(
+        "import importlib.util\n"
+        f"_s = importlib.util.spec_from_file_location('base_cfg', r'{cfg_path('wild')}')\n"
+        "_m = importlib.util.module_from_spec(_s); _s.loader.exec_module(_m)\n"
+        "def get_config():\n"
+        "    c = _m.get_config()\n"
+        f"    c.ZeDO.batch = {N}\n"
+        "    return c\n")
+    model = ScoreModelFC_Adv(load_config(str(cfg_file)), n_joints=17, joint_dim=3, hidden_dim=1024, embed_dim=512, cond_dim=3)
+    sd = {k: torch.tensor(v) for k, v in weights0.items()}
+    sd["sigmas"] = torch.tensor(syn.sigmas_buffer())
+    model.load_state_dict(sd)
+    os.makedirs(tmp_path / "ckpt")
+    torch.save({"model_state_dict": {"module." + k: v for k, v in model.state_dict().items()},
+                "ema": ExponentialMovingAverage(model.parameters(), decay=0.9999).state_dict(), "step": 1},
+               tmp_path / "ckpt" / "c.pth")
+    monkeypatch.chdir(tmp_path)
+    a = inf.parse_args(["prog", "--config", str(cfg_file), "--ckpt_dir", "ckpt", "--ckpt_name", "c.pth", "--hypo", str(H),
+                        "--oil_iterations", str(S), "--data", "poses.npz", "--eval", "--out", "res.npy"])
+    res, errs = inf.main(a)
+    assert res.shape == (N, H, 17, 3) and np.array_equal(np.load("res.npy"), res)
+    cfgw = load_config(str(cfg_file)).ZeDO
+    pipe = Pipeline(weights0, ZeDOConfig(cfgw.IPO_iterations, cfgw.IPO_keylist, cfgw.RotAxes, cfgw.IPO_T, cfgw.IPO_minScaleT,
+                                         cfgw.IPO_maxScaleT, S, cfgw.sampling_eps, 0.1, 1000, 0.1, 20.0), "cuda")
+    x, _ = pipe.load(cl, d["db_2d"], d["camera_param"]).run()
+    assert np.array_equal(x.reshape(H, N, 17, 3).permute(1, 0, 2, 3).cpu().numpy(), res)      # same kernels, same bits
+    assert errs is not None and all(np.isfinite(e) for e in errs) and errs[1] <= errs[0] + 1e-9
+    b = inf.parse_args(["prog", "--config", str(cfg_file), "--ckpt_dir", "ckpt", "--ckpt_name", "c.pth", "--hypo", str(H),
+                        "--oil_iterations", str(S), "--data", "poses.npz", "--out", "res2.npy"])
+    res2, errs2 = inf.main(b)
+    assert errs2 is None and np.array_equal(res2, res)
