@@ -93,6 +93,28 @@ int main(int argc, char **argv) {
         printf("rows %d: hidden alone %.1f us, light alone %.1f us, both on two streams %.1f us (sum %.1f)\n", M, th, tl, tb, th + tl);
         return 0;
     }
+    if (argc > 2 && atoi(argv[2]) == -2) {   // two independent half-batch chains on two streams vs one full-batch chain
+        hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+        const int half = (M / 2 / 256) * 256;
+        LayerArgs lo = a, hi = a; lo.Mp = half; hi.Mp = M - half; hi.X = a.X + (size_t)half * K; hi.out = a.out + (size_t)half * N;
+        auto run2 = [&](int mode) -> float {
+            for (int rep = 0; rep < 2; ++rep) {
+                if (rep == 1) hipDeviceSynchronize();
+                auto t0 = std::chrono::high_resolution_clock::now();
+                for (int r = 0; r < 200; ++r) {
+                    const int epi = (r & 1) ? EPI_GN_SILU_RES : EPI_GN_SILU;
+                    if (mode == 0) launch_layer(a, epi, s1);
+                    else { launch_layer(lo, epi, s1); launch_layer(hi, epi, s2); }
+                }
+                hipDeviceSynchronize();
+                if (rep == 1) return std::chrono::duration<float, std::micro>(std::chrono::high_resolution_clock::now() - t0).count() / 200;
+            }
+            return 0.f;
+        };
+        const float t1 = run2(0), t2 = run2(1), t1b = run2(0), t2b = run2(1);
+        printf("rows %d: one chain %.1f / %.1f us per layer; two half-batch chains on two streams %.1f / %.1f us\n", M, t1, t1b, t2, t2b);
+        return 0;
+    }
     // CPU reference (double) for GN+SiLU on a sample of rows spread over the whole batch
     std::vector<int> rows;
     for (int r = 0; r < M; r += 997) rows.push_back(r);
