@@ -172,14 +172,19 @@ def main():
             ach = flop_launch / (hid["avg_ms"] * 1e-3) / 1e12
             traffic = None
             tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC pass, collected separately
+            mfma_busy = None
             if os.path.exists(tp):
-                traffic = json.load(open(tp)).get("hidden_dense_bytes_per_launch")
+                tj = json.load(open(tp))
+                traffic = tj.get("hidden_dense_bytes_per_launch")
+                mfma_busy = {k: round(v["mfma_util"], 4) for k, v in tj.get("kernels", {}).items()
+                             if k.startswith("layer_pair_kernel") and "mfma_util" in v} or None
             roof = dict(bound="mfma", kernel="zedo::layer_pair_kernel<{GN_SILU|GN_SILU_RES}> (128x128 tiles, 2 workgroups per CU, + 32x128 remainder tiles in the same launch): "
                                              "one 1024x1024 dense layer + GroupNorm + SiLU [+ residual] over all rows",
                         achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                         flop_per_launch=flop_launch, avg_launch_ms=round(hid["avg_ms"], 4),
-                        sampled_launches=hid["samples"], launches=hid["launches"])
+                        sampled_launches=hid["samples"], launches=hid["launches"],
+                        mfma_busy_pmc=mfma_busy)   # SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles, from the committed PMC pass
         line = {
             "metric": "poses/sec (1000-step sampler, H=50)", "value": round(poses_per_s, 3), "unit": "poses/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
