@@ -248,6 +248,22 @@ def test_min_mpjpe_golden(zh, golden):
         assert abs(best[n].item() - ref) < 1e-12 and best_h[n].item() == min(hs, key=lambda h: full[n, h])
 
 
+@pytest.mark.parametrize("B", [1300, 2304, 4096, 5000, 7000, 8500, 10000, 16384])
+def test_score_network_every_launch_shape(zh, W, weights0, B):
+    """Row counts that take each tile-selection branch of the dense layers (32 / 64 / 128-row tiles chosen by the
+    cost model below one round, the pair launch with a short and a long remainder, exact rounds); the oracle is
+    evaluated on a sample of rows (rows are independent) including the last ones."""
+    import zedo_oracle as O
+    rng = np.random.default_rng(B)
+    x = (0.3 * rng.standard_normal((B, 17, 3))).astype(np.float32)
+    pick = np.unique(np.concatenate([rng.integers(0, B, 48), np.arange(B - 40, B), np.arange(0, 8)]))
+    s = zh.Schedule(W, np.array([0.07], np.float32))
+    eps = zh.score_eps(W, s, 0, dev(x)).cpu().numpy()
+    ref = O.score_model_forward(weights0, x[pick], np.float32(0.07) * np.float32(999))
+    np.testing.assert_allclose(eps[pick], ref, atol=3e-6, rtol=0)
+    assert np.isfinite(eps).all()
+
+
 # ---------------------------------------------------------------- full-size properties
 
 def test_rows_are_independent_at_full_size(zh, W):
@@ -269,6 +285,10 @@ def test_rows_are_independent_at_full_size(zh, W):
     zh.oil_run(W, sched, xs, geom, Ts, 0, S, 2, row_offset=lo)
     assert torch.equal(x[lo:hi], xs) and torch.equal(T[lo:hi], Ts)
     assert torch.isfinite(x).all()
+    lo2, hi2 = 49900, H * N                                   # rows served by the remainder tiles of the pair launches
+    xs2, Ts2 = dev(x0[lo2:hi2]), dev(T0[lo2:hi2])
+    zh.oil_run(W, sched, xs2, geom, Ts2, 0, S, 2, row_offset=lo2)
+    assert torch.equal(x[lo2:hi2], xs2) and torch.equal(T[lo2:hi2], Ts2)
     # after the reprojection correction every joint lies on its ray: the correction is idempotent
     g1 = zh.reproj_grad(x, geom, T, False)
     x2 = x + g1
