@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Run the fused OIL loop repeatedly on the same full-size input and require bit-identical results
+(a race in the LDS ring / DMA waits of the dense-layer kernel shows up as a rare differing tile).
+usage: python tools/soak_determinism.py [repeats] [steps]"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "zedo-release_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import zedo_hip as zh
+import zedo_oracle as O
+from lib.dataset import synthetic as syn
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+dev = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")
+seen = {}
+for (H, N) in ((50, 1015), (50, 886), (7, 1015), (3, 333)):
+    d = syn.make_poses(N, seed=1)
+    rng = np.random.default_rng(11)
+    x0 = (0.25 * rng.standard_normal((H * N, 17, 3))).astype(np.float32)
+    T0 = np.tile(d["db_3d"][:, 0, :], (H, 1)).astype(np.float32)
+    W = zh.Weights(syn.make_weights(0))
+    sched = zh.Schedule(W, O.oil_timestamps(S))
+    geom = zh.reproj_prepare(dev(d["db_2d"][:, :, :2]), dev(d["camera_param"]), dev(d["db_2d"][:, :, 2]))
+    digests = set()
+    for r in range(reps):
+        x, T = dev(x0), dev(T0)
+        zh.oil_run(W, sched, x, geom, T, 0, S, S // 5)
+        digests.add(hashlib.sha256(x.cpu().numpy().tobytes() + T.cpu().numpy().tobytes()).hexdigest())
+    print(f"rows {H * N}: {reps} runs x {S} steps -> {len(digests)} distinct result(s)")
+    seen[H * N] = len(digests)
+sys.exit(0 if all(v == 1 for v in seen.values()) else 1)
