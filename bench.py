@@ -89,6 +89,17 @@ def cpu_baseline(weights, cfg_kw, seed):
                        f"extrapolated to H={N_HYPO}, S={S_OIL}")
 
 
+def selection_digest(out):
+    """sha256 over the per-pose best errors and winning hypothesis indices of both protocols (bit-exact
+    comparison of two runs, e.g. with and without the RCCL exchange step)."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in ("p1", "p2"):
+        h.update(out[k][0].cpu().numpy().tobytes())
+        h.update(out[k][1].cpu().numpy().astype(np.int32).tobytes())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,7 +119,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    use_dist = world > 1 or os.environ.get("ZEDO_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank test of the RCCL path
+    from zedo_hip.pipeline import force_dist
+    use_dist = world > 1 or force_dist()   # ZEDO_FORCE_DIST=1: 1-rank test of the RCCL path
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -173,6 +185,7 @@ def main():
             traffic = None
             tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC pass, collected separately
             mfma_busy = None
+            tj = {}
             if os.path.exists(tp):
                 tj = json.load(open(tp))
                 traffic = tj.get("hidden_dense_bytes_per_launch")
@@ -184,7 +197,13 @@ def main():
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                         flop_per_launch=flop_launch, avg_launch_ms=round(hid["avg_ms"], 4),
                         sampled_launches=hid["samples"], launches=hid["launches"],
-                        mfma_busy_pmc=mfma_busy)   # SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles, from the committed PMC pass
+                        mfma_busy_pmc=mfma_busy,   # SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles
+                        # achieved / avg_launch_ms are measured in THIS run; traffic and mfma_busy_pmc are not:
+                        # they are replayed from the committed counter pass of the same command
+                        measured_live=["achieved", "frac", "avg_launch_ms", "sampled_launches", "launches"],
+                        replayed={"fields": ["traffic", "mfma_busy_pmc"],
+                                  "source": "profiles/hbm_traffic.json" if traffic is not None else None,
+                                  "collected": tj.get("collected") if traffic is not None else None})
         line = {
             "metric": "poses/sec (1000-step sampler, H=50)", "value": round(poses_per_s, 3), "unit": "poses/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
@@ -195,8 +214,12 @@ def main():
                        "rows_per_gpu": rows, "poses_total": N_total, "sharding": f"rows over {world} rank(s)"},
             "pose_hyp_steps_per_s": round(row_steps_per_s, 1),
             "end_to_end_tflops": round(row_steps_per_s * FLOP_PER_ROW_STEP / 1e12, 2),
+            # all six layers' algorithmic FLOP over the wall time of the whole pass (IPO, reprojection, selection,
+            # launch gaps included) against the same fp32-MFMA peak
+            "end_to_end_frac": round(row_steps_per_s * FLOP_PER_ROW_STEP / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
             "mpjpe_best_of_H_m": round(float(out["p1"][0].mean().item()), 6),
             "pa_mpjpe_best_of_H_m": round(float(out["p2"][0].mean().item()), 6),
+            "selection_sha16": selection_digest(out),
             "roofline": roof,
             "kernel_time_ms_sampled_avg": {k: (round(v["avg_ms"], 4) if v["avg_ms"] else None) for k, v in prof.items()},
         }

@@ -14,6 +14,10 @@
  *    it and nothing synchronises unless stated;
  *  - functions write only caller-allocated outputs and the caller-provided workspace; the only
  *    library-owned device memory lives inside zedo_weights_t / zedo_schedule_t handles;
+ *  - calls on distinct streams may run concurrently (one process per GPU is the intended use; a second device
+ *    in the same process works: launch attributes are cached per device).  Process-wide state exists only
+ *    outside the data path: the zedo_profile_* diagnostic (one session at a time, not thread safe) and the
+ *    ZEDO_CHUNK_ROWS environment value, read once;
  *  - rows are hypothesis-major: global row g = h*N + n (h = hypothesis, n = pose) - the order in
  *    which the reference's hypothesis loop produces them (run/opt_main.py:166-222).  A call may
  *    hold any contiguous shard of the global rows: local row b is global row row_offset + b, so
@@ -30,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ZEDO_ABI_VERSION 1
+#define ZEDO_ABI_VERSION 2
 
 #define ZEDO_OK 0
 #define ZEDO_E_BADARG (-1)      /* NULL pointer, non-positive size, unsupported dimension */
@@ -129,14 +133,26 @@ int zedo_oil_run(const zedo_weights_t *w, const zedo_schedule_t *s, float *d_x, 
  * when rows are sharded).  d_x0 [H,J,3] (centred cluster poses), d_uv [N,J,2], d_K [N,3,3],
  * h_keylist[k] joint indices, axes_mask bit0=x bit1=y bit2=z.
  * Outputs: d_R [B,3,3], d_T [B,3] = T0*clamp(scale), optional d_q [B,4], d_scale [B] (may be NULL).
+ * H = number of hypotheses in d_x0: row_offset + B > H*N is rejected (ZEDO_E_BADARG).
  */
 int zedo_ipo_fit(const float *d_x0, const float *d_uv, const float *d_K, const int *h_keylist, int k,
                  int axes_mask, float ipo_T, float min_scale, float max_scale, int iters, double normaliser,
-                 float *d_R, float *d_T, float *d_q, float *d_scale, int B, int N, int J, long long row_offset,
+                 float *d_R, float *d_T, float *d_q, float *d_scale, int B, int H, int N, int J, long long row_offset,
                  void *stream);
 
-/* x[b] = R[b] . x0[h(b)]   (run/opt_main.py:201).  d_x [B,J,3]. */
-int zedo_rotate_init(const float *d_x0, const float *d_R, float *d_x, int B, int N, int J, long long row_offset,
+/* The same fit, resumable (parity instrument: one Adam iteration from a captured optimiser state).
+ * d_state [B,15] fp32 = (param[5], exp_avg[5], exp_avg_sq[5]) in the order (rot_vect, rot_vect_x, _y, _z, scale),
+ * i.e. torch.optim.Adam's per-parameter state (opt_main.py:183).  it_begin = iterations already applied to
+ * d_state; with it_begin == 0 the input content is ignored and the fit starts from RotOpt's initial values
+ * (simple_zeroshot_opt.py:11-16).  Runs iterations [it_begin, it_begin + iters) and writes the state back.
+ */
+int zedo_ipo_fit_resume(const float *d_x0, const float *d_uv, const float *d_K, const int *h_keylist, int k,
+                        int axes_mask, float ipo_T, float min_scale, float max_scale, int iters, double normaliser,
+                        float *d_R, float *d_T, float *d_q, float *d_scale, float *d_state, int it_begin, int B, int H,
+                        int N, int J, long long row_offset, void *stream);
+
+/* x[b] = R[b] . x0[h(b)]   (run/opt_main.py:201).  d_x [B,J,3]; d_x0 [H,J,3]. */
+int zedo_rotate_init(const float *d_x0, const float *d_R, float *d_x, int B, int H, int N, int J, long long row_offset,
                      void *stream);
 
 /* ---- hypothesis selection: eval_multi inner loops (lib/dataset/h36m.py:394-417, pw3d.py:302-331) ----

@@ -304,7 +304,8 @@ def ipo_fit(x0k, T0, K, condk, axes="z", minT=0.5, maxT=2.0, iters=500, normalis
 
     x0k [B,k,3] = cluster pose restricted to IPO_keylist, condk [B,k,2], T0 [B,1,3].
     Returns (R [B,3,3], T [B,1,3] = T0*clamp(scale), q [B,4], scale [B], last loss).
-    trace: optional list receiving (q, scale, loss) copies after each iteration.
+    trace: optional list receiving (q, scale, loss, exp_avg_q, exp_avg_sq_q, exp_avg_scale, exp_avg_sq_scale,
+    |residual| [B,k,2] of the forward that produced this iteration's gradient) copies after each iteration.
     """
     x0k = np.asarray(x0k, dtype=dtype)
     condk = np.asarray(condk, dtype=dtype)
@@ -320,7 +321,7 @@ def ipo_fit(x0k, T0, K, condk, axes="z", minT=0.5, maxT=2.0, iters=500, normalis
     ms, vs = np.zeros_like(scale), np.zeros_like(scale)
     loss = dtype(0)
     for it in range(1, iters + 1):
-        loss, gq, gs, _ = ipo_loss_and_grads(q, scale, x0k, T0, K, condk, axes, minT, maxT, normaliser)
+        loss, gq, gs, uv_ = ipo_loss_and_grads(q, scale, x0k, T0, K, condk, axes, minT, maxT, normaliser)
         # torch.optim.Adam single-tensor update (no weight decay / amsgrad)
         step_size = dtype(lr / (1 - b1 ** it))
         bc2_sqrt = dtype(math.sqrt(1 - b2 ** it))
@@ -331,7 +332,8 @@ def ipo_fit(x0k, T0, K, condk, axes="z", minT=0.5, maxT=2.0, iters=500, normalis
             denom = np.sqrt(v) / bc2_sqrt + dtype(adam_eps)
             p -= step_size * (m / denom)
         if trace is not None:
-            trace.append((q.copy(), scale.copy(), dtype(loss)))
+            trace.append((q.copy(), scale.copy(), dtype(loss), mq.copy(), vq.copy(), ms.copy(), vs.copy(),
+                          np.abs(uv_ - condk)))
     R = quaternion_to_matrix(q)
     T = (T0 * np.clip(scale, dtype(minT), dtype(maxT))[:, None])[:, None, :]
     return R.astype(dtype), T.astype(dtype), q, scale, loss

@@ -96,3 +96,27 @@ def test_skipose_reader_needs_h5py_and_says_so(tmp_path):
     else:
         with pytest.raises(OSError):
             skiPose(str(tmp_path), "test")
+
+
+@pytest.mark.parametrize("tag,kw", [("abs", dict(abs_coord=True)), ("rel_s5", dict(abs_coord=False, sample_interval=5))])
+def test_skipose_reader_matches_the_reference(golden, monkeypatch, tag, kw):
+    """the SkiPose reader (reference lib/dataset/skiPose.py:119-157).  h5py is not installed
+    offline, so BOTH readers - the reference's when the fixture was captured (tools/gen_golden.py::gen_3dhp_ski)
+    and this repo's here - read the synthetic ski_test.h5 through the same stand-in (tools/ref_stubs/h5py.py:
+    File[key][index] served from an .npz archive).  What is pinned is the parsing arithmetic: x256 crop scaling,
+    cam[2,2] = 1, the ones column of db_2d, float32 casts, root-centring, sampling, image names."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("h5py", os.path.join(root, "tools", "ref_stubs", "h5py.py"))
+    fake = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fake)
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    from lib.dataset.skiPose import skiPose
+    g = golden("hp3d_ski")
+    ds = skiPose(os.path.join(ASSETS, "ski"), "test", gt2d=True, flip=False, **kw)
+    for name in ("db_2d", "db_3d", "camera_param"):
+        assert same(getattr(ds, name), g[f"skir_{tag}_{name}"]), (tag, name, getattr(ds, name).dtype)
+    # like the reference, _sample() leaves image_name unsampled (skiPose.py:111-117)
+    assert [str(s) for s in ds.image_name] == [str(s) for s in g[f"skir_{tag}_image_name"]]
+    assert len(ds) == len(ds.db_2d) == ds.real_data_len

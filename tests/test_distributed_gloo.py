@@ -67,6 +67,46 @@ def test_two_rank_min_reduction_equals_unsharded(tmp_path, protocol2):
     assert np.array_equal(r["idx"], r["ref_idx"])          # lowest hypothesis index wins ties, like np.argmin
 
 
+def _worker_gather_nan(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "zedo-release_amd"))
+    import torch.distributed as dist
+    from zedo_hip.pipeline import gather_row_shards, reduce_min_over_ranks, shard_rows
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    # all-gather of uneven contiguous row shards (run.inference): 3 ranks x 5 rows cover 13 rows as 5 + 5 + 3
+    total = 13
+    full = torch.arange(total * 17 * 3, dtype=torch.float32).reshape(total, 17, 3)
+    lo, n = shard_rows(total, rank, world)
+    got = gather_row_shards(full[lo:lo + n].clone(), total)
+    ok_gather = bool(torch.equal(got, full))
+    # more ranks than rows: the last rank holds an empty shard
+    lo2, n2 = shard_rows(2, rank, world)
+    got2 = gather_row_shards(full[lo2:lo2 + n2].clone(), 2)
+    ok_empty = bool(torch.equal(got2, full[:2])) and (n2 == 0) == (rank == 2)
+    # NaN follows np.amin / np.argmin across ranks; a pose nobody holds stays (+inf, -1)
+    inf, nan = float("inf"), float("nan")
+    best = [torch.tensor([0.5, nan, 0.3, inf, nan], dtype=torch.float64),
+            torch.tensor([0.4, 0.1, nan, inf, nan], dtype=torch.float64),
+            torch.tensor([0.4, 0.2, 0.3, inf, 0.0], dtype=torch.float64)][rank]
+    idx = [torch.tensor([0, 1, 0, -1, 1], dtype=torch.int32), torch.tensor([2, 3, 3, -1, 2], dtype=torch.int32),
+           torch.tensor([4, 5, 4, -1, 5], dtype=torch.int32)][rank]
+    gb, gi = reduce_min_over_ranks(best, idx)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "gn.npz"), ok_gather=ok_gather, ok_empty=ok_empty, best=gb.numpy(), idx=gi.numpy())
+    ok = torch.tensor([float(ok_gather and ok_empty)])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    assert ok.item() == 1.0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_gather_of_uneven_shards_and_nan_minimum(tmp_path):
+    mp.spawn(_worker_gather_nan, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    r = np.load(tmp_path / "gn.npz")
+    assert bool(r["ok_gather"]) and bool(r["ok_empty"])
+    np.testing.assert_array_equal(r["best"], np.array([0.4, np.nan, np.nan, np.inf, np.nan]))
+    assert list(r["idx"]) == [2, 1, 3, -1, 1]       # lowest index at the minimum; lowest NaN index; nobody: -1
+
+
 def test_single_process_is_identity():
     from zedo_hip.pipeline import reduce_min_over_ranks
     b, i = torch.tensor([1.0, 2.0]), torch.tensor([3, 4], dtype=torch.int32)

@@ -30,7 +30,7 @@ def dev(a, dtype=torch.float32):
 
 
 def test_abi_version(zh):
-    assert zh.abi_version() == 1
+    assert zh.abi_version() == 2
 
 
 def test_schedule_tables(zh, W, weights0, golden):
@@ -187,6 +187,18 @@ IPO_CASES = [(N, axes, kname) for N in (8, 64) for axes in ("z", "xyz") for knam
 
 @pytest.mark.parametrize("N,axes,kname", IPO_CASES)
 def test_ipo_trajectory_golden(zh, golden, N, axes, kname):
+    """IPO against the reference's own parameter trajectories (tools/gen_golden.py::gen_ipo, opt_main.py:180-195).
+
+    Adam on an L1 loss is chaotic: a residual whose sign differs between two implementations moves a parameter by
+    2 x lr x (1 - beta1) = 0.02 in one iteration.  The reference run in fp32 is itself gap(it) = |ref32 - ref64| away
+    from its own fp64 run (RotOpt().double(): 2.4e-8 after 1 iteration, 1e-7..6e-7 after 5, 1e-5..1e-3 after 30, up
+    to 5e-2 after 50 - by then single poses have taken a different sign somewhere, in ref32 as in any other fp32
+    implementation; the numpy oracle shows the same events at the same iterations).  Criterion, with the fp64 run as
+    arbiter like the OIL loop's: iteration 1 within 1e-7, iteration 5 within 2e-6, iterations 1..30 the worst pose
+    within 2 x gap + 1e-7; iterations 31..50, where the worst pose measures a sign event and not arithmetic, the
+    MEDIAN pose within 2 x the median gap + 1e-7 and every pose within 0.1.  What the kernel does at every state on
+    the way is pinned separately by test_ipo_single_iterations_from_reference_state.  All 50 achieved deviations
+    go to the parity report."""
     import zedo_oracle as O
     g = golden("ipo")
     kl, ipoT, minT = ([0, 1, 4], 3.0, 0.5) if kname == "h36m" else (list(range(17)), 8.0, 0.2)
@@ -195,25 +207,94 @@ def test_ipo_trajectory_golden(zh, golden, N, axes, kname):
     K = dev(g[f"K_{N}"])
     x0 = dev(g["cluster0"][None])
     norm = N * len(kl) * 2
-    for it, tol in ((1, 2e-6), (5, 2e-5), (20, 2e-3)):
+    q32, s32 = g[f"trace_q_{tag}"], g[f"trace_scale_{tag}"]
+    q64, s64 = g[f"trace_q64_{tag}"], g[f"trace_scale64_{tag}"]
+    rows = []
+    for it in range(1, q64.shape[0] + 1):
         R, T, q, sc = zh.ipo_fit(x0, uv, K, kl, axes, ipoT, minT, 2.0, it, norm, N, return_params=True)
-        np.testing.assert_allclose(q.cpu().numpy(), g[f"trace_q_{tag}"][it - 1], atol=tol, rtol=0)
-        np.testing.assert_allclose(sc.cpu().numpy(), g[f"trace_scale_{tag}"][it - 1], atol=tol, rtol=0)
+        qn, sn = q.cpu().numpy().astype(np.float64), sc.cpu().numpy().astype(np.float64)
+        s64i, s32i = s64[it - 1].reshape(-1), s32[it - 1].reshape(-1).astype(np.float64)
+        dp = np.maximum(np.abs(qn - q64[it - 1]).max(1), np.abs(sn - s64i))                     # per pose
+        gp = np.maximum(np.abs(q32[it - 1] - q64[it - 1]).max(1), np.abs(s32i - s64i))
+        d32 = max(np.abs(qn - q32[it - 1]).max(), np.abs(sn - s32i).max())
+        rows.append(dict(it=it, hip_vs_ref64=float(dp.max()), hip_vs_ref32=float(d32), ref32_vs_ref64=float(gp.max()),
+                         hip_vs_ref64_median=float(np.median(dp)), ref32_vs_ref64_median=float(np.median(gp))))
+    _report(f"ipo_{tag}", rows)
+    for r in rows:
+        if r["it"] <= 30:
+            assert r["hip_vs_ref64"] <= 2.0 * r["ref32_vs_ref64"] + 1e-7, r
+        else:
+            assert r["hip_vs_ref64_median"] <= 2.0 * r["ref32_vs_ref64_median"] + 1e-7 and r["hip_vs_ref64"] <= 0.1, r
+    assert rows[0]["hip_vs_ref64"] <= 1e-7 and rows[4]["hip_vs_ref64"] <= 2e-6, (rows[0], rows[4])
     # T0 (0 iterations): scale = 1
     R, T = zh.ipo_fit(x0, uv, K, kl, axes, ipoT, minT, 2.0, 0, norm, N)
     np.testing.assert_allclose(T.cpu().numpy(), g[f"T0_{tag}"].reshape(N, 3), atol=1e-6, rtol=0)
     assert np.allclose(R.cpu().numpy(), np.eye(3)[None], atol=0)
-    # 500 iterations: chaotic per pose, so compare the achieved loss (oracle forward on the HIP parameters)
+    # 500 iterations: the trajectories have decorrelated per pose by then, so compare what the fit is for - the
+    # achieved loss (oracle forward on the HIP parameters) against the reference's final loss
     R, T, q, sc = zh.ipo_fit(x0, uv, K, kl, axes, ipoT, minT, 2.0, 500, norm, N, return_params=True)
     cond = g[f"db2d_{N}"][:, :, :2]
     x0n = np.broadcast_to(g["cluster0"][None], (N, 17, 3)).astype(np.float32)
     T0 = O.ipo_init_T(cond, g[f"K_{N}"], ipoT).reshape(N, 3)
     loss, _, _, _ = O.ipo_loss_and_grads(q.cpu().numpy(), sc.cpu().numpy(), x0n[:, kl], T0, g[f"K_{N}"], cond[:, kl],
                                          axes, minT, 2.0, norm)
+    _report(f"ipo_{tag}_final", [dict(loss_hip=float(loss), loss_ref=float(g[f"loss_{tag}"]))])
     assert abs(loss - g[f"loss_{tag}"]) <= 0.05 * g[f"loss_{tag}"]
     Rn = R.cpu().numpy()
     assert np.allclose(np.einsum("bij,bkj->bik", Rn, Rn), np.eye(3)[None], atol=1e-5)
     np.testing.assert_allclose(Rn, O.quaternion_to_matrix(q.cpu().numpy()), atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("N,axes,kname", IPO_CASES)
+def test_ipo_single_iterations_from_reference_state(zh, golden, N, axes, kname):
+    """Every one of the first 50 Adam iterations, taken on its own from the REFERENCE's optimiser state.
+
+    Trajectories of this fit decorrelate (a residual whose sign two implementations disagree on moves a parameter by
+    2 x lr x (1 - beta1)), so a trajectory comparison alone cannot tell a wrong gradient term from chaos.  Here each
+    iteration starts from the state (parameters, exp_avg, exp_avg_sq) of the reference's fp64 run - reproduced by the
+    fp64 oracle, which is first checked against the reference's own fp64 trace (tools/gen_golden.py::gen_ipo,
+    RotOpt().double(), opt_main.py:180-195) to 1e-8 - runs ONE iteration of ipo_kernel (zedo_ipo_fit_resume) and must
+    land on the reference's next state: |delta parameter| <= 5e-7 for every pose whose residuals are all
+    sign-unambiguous (|e| >= 1e-3 px; the root joint sits on the ray through the origin and contributes no gradient,
+    it is not counted).  Ambiguous (pose, iteration) pairs are counted and reported, not compared."""
+    import zedo_oracle as O
+    g = golden("ipo")
+    kl, ipoT, minT = ([0, 1, 4], 3.0, 0.5) if kname == "h36m" else (list(range(17)), 8.0, 0.2)
+    tag = f"{N}_{axes}_{kname}"
+    cond, Kn = g[f"db2d_{N}"][:, :, :2], g[f"K_{N}"]
+    uv, K, x0 = dev(cond), dev(Kn), dev(g["cluster0"][None])
+    norm = N * len(kl) * 2
+    c64, K64 = cond.astype(np.float64), Kn.astype(np.float64)
+    x64 = np.broadcast_to(g["cluster0"][None], (N, 17, 3)).astype(np.float64)
+    tr = []
+    O.ipo_fit(x64[:, kl], O.ipo_init_T(c64, K64, ipoT, dtype=np.float64), K64, c64[:, kl], axes, minT, 2.0, 50,
+              normaliser=norm, dtype=np.float64, trace=tr)
+    for it in range(50):                                   # the arbiter itself is the reference's fp64 run
+        assert np.abs(tr[it][0] - g[f"trace_q64_{tag}"][it]).max() <= 1e-8
+        assert np.abs(tr[it][1] - g[f"trace_scale64_{tag}"][it].reshape(-1)).max() <= 1e-8
+
+    def pack(q, sc, mq, vq, ms, vs):
+        return np.concatenate([q, sc[:, None], mq, ms[:, None], vq, vs[:, None]], axis=1)
+    z4, z1 = np.zeros((N, 4)), np.zeros(N)
+    q0 = z4.copy(); q0[:, 0] = 1
+    states = [pack(q0, np.ones(N), z4, z4, z1, z1)] + [pack(t[0], t[1], t[3], t[4], t[5], t[6]) for t in tr]
+    moving = np.abs(g["cluster0"][kl]).max(-1) > 0          # joints off the root
+    worst, n_amb, worst_m, worst_v = 0.0, 0, 0.0, 0.0
+    for it in range(50):
+        st = dev(states[it].astype(np.float32))
+        zh.ipo_fit(x0, uv, K, kl, axes, ipoT, minT, 2.0, 1, norm, N, state=st, it_begin=it)
+        out = st.cpu().numpy().astype(np.float64)
+        clear = tr[it][7][:, moving, :].reshape(N, -1).min(1) >= 1e-3
+        n_amb += int((~clear).sum())
+        d = np.abs(out - states[it + 1])
+        worst = max(worst, float(d[clear, :5].max()))
+        worst_m = max(worst_m, float(d[clear, 5:10].max()))
+        worst_v = max(worst_v, float((d[clear, 10:] / (np.abs(states[it + 1][clear, 10:]) + 1e-12)).max()))
+        assert d[clear, :5].max() <= 5e-7, (it, d[clear, :5].max())
+    _report(f"ipo_resync_{tag}", [dict(iterations=50, poses=N, ambiguous_pose_iterations=n_amb,
+                                        max_param_delta=worst, max_exp_avg_delta=worst_m,
+                                        max_exp_avg_sq_rel_delta=worst_v)])
+    assert n_amb <= 0.05 * 50 * N, n_amb
 
 
 def test_rotate_init(zh):
@@ -246,6 +327,39 @@ def test_min_mpjpe_golden(zh, golden):
         hs = [h for h in range(H) if lo <= h * N + n < hi]
         ref = min(full[n, h] for h in hs)
         assert abs(best[n].item() - ref) < 1e-12 and best_h[n].item() == min(hs, key=lambda h: full[n, h])
+
+
+@pytest.mark.parametrize("tag", ["planar_pred", "planar_gt"])
+def test_min_mpjpe_rank2_alignment_matches_the_reference_value(zh, golden, tag):
+    """Planar prediction / planar ground truth (exactly in z = 0, and in a random plane to float32 rounding): the
+    SVD of the alignment has a zero singular value whose direction sign is arbitrary in numpy/LAPACK, but the
+    ERROR is the same for either sign (tests/test_oracle_golden.py shows why); the kernel's choice must therefore
+    reproduce the reference's error values (tools/gen_golden.py::gen_eval, transforms.py:42-127)."""
+    g = golden("eval_multi")
+    G, P, ref = g[f"deg_{tag}_gt"], g[f"deg_{tag}_pred"], g[f"deg_{tag}_err_p2"]
+    err, best, idx = zh.min_mpjpe(dev(P.astype(np.float32)), dev(G - 0.0, torch.float64), len(G), procrustes=True)
+    _report(f"procrustes_rank2_{tag}", [dict(max_abs_err_delta=float(np.abs(err.cpu().numpy() - ref).max()))])
+    np.testing.assert_allclose(err.cpu().numpy(), ref, atol=3e-7, rtol=0)
+
+
+def test_min_mpjpe_nan_hypothesis_poisons_the_pose_like_numpy(zh, golden):
+    """np.amin / np.argmin (lib/dataset/h36m.py:411-412) return NaN and the first NaN index when any hypothesis of
+    a pose is NaN; a diverged sample must not be masked by a finite minimum."""
+    g = golden("eval_multi")
+    preds = g["preds"].copy()
+    N, H = preds.shape[:2]
+    preds[3, 2, 5, 1] = np.nan            # pose 3: hypothesis 2
+    preds[7, 4] = np.nan                  # pose 7: hypotheses 1 and 4 -> first NaN index 1
+    preds[7, 1, 0, 0] = np.nan
+    rows = np.ascontiguousarray(np.swapaxes(preds, 0, 1).reshape(H * N, 17, 3))
+    gt = (g["gt_mm_h36m"] - g["gt_mm_h36m"][:, 0:1]) / 1000.0
+    for p2 in (False, True):
+        err, best, best_h = zh.min_mpjpe(dev(rows), dev(gt, torch.float64), N, procrustes=p2)
+        e = err.cpu().numpy().reshape(H, N).T
+        assert np.isnan(e[3, 2]) and np.isnan(e[7, 1]) and np.isnan(e[7, 4]) and np.isnan(e).sum() == 3
+        np.testing.assert_array_equal(best.cpu().numpy(), np.amin(e, axis=1))     # NaN == NaN under assert_array_equal
+        assert np.array_equal(best_h.cpu().numpy(), np.argmin(e, axis=1))
+        assert best_h[3].item() == 2 and best_h[7].item() == 1
 
 
 @pytest.mark.parametrize("B", [1300, 2304, 4096, 5000, 7000, 8500, 10000, 16384])
@@ -350,6 +464,15 @@ def test_bad_arguments_are_rejected(zh, W):
     assert lib.zedo_sde_step(W._h, s._h, 0, P(x), 4, P(ws), 16, None) == -3
     assert lib.zedo_oil_run(W._h, s._h, P(x), None, None, 0, 5, 1, 4, 4, 0, P(ws), ws.numel(), None) == -1
     assert lib.zedo_workspace_bytes(0) == 0
+    # rows beyond H*N would index the cluster poses out of bounds (H = 2 hypotheses x N = 3 poses, 7 rows asked)
+    x0 = torch.zeros(2, 17, 3, device="cuda"); uv = torch.zeros(3, 17, 2, device="cuda")
+    K = torch.eye(3, device="cuda").repeat(3, 1, 1).contiguous()
+    with pytest.raises(zh.ZedoError):
+        zh.ipo_fit(x0, uv, K, [0, 1, 4], "z", 3.0, 0.5, 2.0, 1, 18, 7)
+    with pytest.raises(zh.ZedoError):
+        zh.ipo_fit(x0, uv, K, [0, 1, 4], "z", 3.0, 0.5, 2.0, 1, 18, 4, row_offset=3)
+    with pytest.raises(zh.ZedoError):
+        zh.rotate_init(x0, torch.zeros(7, 3, 3, device="cuda"), 3)
     with pytest.raises(zh.ZedoError):
         zh.Schedule(W, np.zeros(0, np.float32))
     with pytest.raises(zh.ZedoError):       # wrong parameter count

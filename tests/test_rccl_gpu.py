@@ -1,0 +1,91 @@
+"""RCCL on the GPU with ONE rank (-m gpu): every collective of the sharded path - the process group over
+backend "nccl" (= RCCL on ROCm), the fp64 MIN and int64 MIN all-reduces of reduce_min_over_ranks, the all-gather
+of run.inference, the barrier / MAX of bench.py - executed on an MI355X in fresh child processes with
+RANK=0 WORLD_SIZE=1 ZEDO_FORCE_DIST=1, and compared bit for bit with the same run without a process group.
+The multi-rank arithmetic itself is covered on CPU over gloo (tests/test_distributed_gloo.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _env(dist):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ZEDO_FORCE_DIST", "ZEDO_BENCH_FORCE_DIST"):
+        e.pop(k, None)
+    e["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if dist:
+        e.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", ZEDO_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(_free_port()))
+    return e
+
+
+def _run(cmd, dist, cwd=ROOT):
+    r = subprocess.run(cmd, env=_env(dist), cwd=cwd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def test_bench_exchange_step_on_rccl_is_bit_identical():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--oil", "20", "--poses", "64",
+           "--hypo", "5", "--no-cpu-baseline"]
+    lines = {}
+    for dist in (False, True):
+        out = _run(cmd, dist)
+        lines[dist] = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    a, b = lines[False], lines[True]
+    assert a["n_gpus"] == b["n_gpus"] == 1
+    assert a["selection_sha16"] == b["selection_sha16"], (a["selection_sha16"], b["selection_sha16"])
+    assert a["mpjpe_best_of_H_m"] == b["mpjpe_best_of_H_m"] and a["pa_mpjpe_best_of_H_m"] == b["pa_mpjpe_best_of_H_m"]
+
+
+DRIVER = r'''
+import hashlib, json, os, sys
+import numpy as np
+root = %r
+sys.path.insert(0, os.path.join(root, "zedo-release_amd"))
+import torch
+import run.opt_main as om, run.inference as inf
+cfg = lambda n: os.path.join(root, "zedo-release_amd", "configs", "optim", "concat_pose_optimization_%%s.py" %% n)
+p1, p2 = om.main(om.parse_args(["prog", "--config", cfg("pw3d"), "--hypo", "3", "--synthetic", "40", "--oil_iterations", "20"]))
+if "MASTER_PORT" in os.environ:            # second process group of this process: fresh rendezvous port
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1]); s_.close()
+out = os.path.join(sys.argv[1], "results.npy")
+res, errs = inf.main(inf.parse_args(["prog", "--config", cfg("h36m"), "--hypo", "2", "--synthetic", "30", "--oil_iterations", "10",
+                                     "--eval", "--out", out]))
+import torch.distributed as dist
+print("RESULT " + json.dumps(dict(opt=[repr(p1), repr(p2)], inf=[repr(errs[0]), repr(errs[1])],
+                                  sha=hashlib.sha256(np.load(out).tobytes()).hexdigest(), shape=list(res.shape),
+                                  group_was_used=os.environ.get("ZEDO_FORCE_DIST") == "1")))
+'''
+
+
+def test_drivers_on_rccl_are_bit_identical(tmp_path):
+    """run.opt_main --synthetic and run.inference --synthetic --eval through init_process_group("nccl"): the
+    sharded eval_multi (two MIN all-reduces per protocol) and the all-gather of the inference result."""
+    res = {}
+    for dist in (False, True):
+        d = tmp_path / ("dist" if dist else "plain")
+        d.mkdir()
+        out = _run([sys.executable, "-c", DRIVER % ROOT, str(d)], dist)
+        res[dist] = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res[True]["group_was_used"] and not res[False]["group_was_used"]
+    for k in ("opt", "inf", "sha", "shape"):
+        assert res[False][k] == res[True][k], (k, res[False][k], res[True][k])
+    assert res[True]["shape"] == [30, 2, 17, 3]

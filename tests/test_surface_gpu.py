@@ -171,6 +171,116 @@ def test_fused_driver_full_length_matches_reference(weights0, golden):
     assert abs(p2 - float(d["pa_mpjpe"])) < 5e-5, (p2, float(d["pa_mpjpe"]))
 
 
+def test_reference_loop_through_the_per_step_surface(model, weights0):
+    """The reference's own loop (run/opt_main.py:166-222: RotOpt fit, then per step gradient_field_gen, += and
+    sampling_fn with its host round trip) driven UNCHANGED through the drop-in callables
+    (run._driver.stepwise_loop) must give the rows of the fused pipeline bit for bit, and the sampler must serve
+    every step from ONE whole-loop schedule (no per-call zedo_schedule_create): hits == steps, misses == 0.
+    Also the configuration guard: a sampler configuration the fused pipeline does not implement is reported, not
+    silently run as Euler probability flow."""
+    from lib.algorithms.advanced import sampling, sde_lib
+    from lib.dataset import synthetic as syn
+    from run import _driver
+    from zedo_hip.pipeline import Pipeline, ZeDOConfig
+    cfg = _driver.load_config(cfg_path("h36m"))
+    cfg.sampling.probability_flow = True
+    assert _driver.not_fused_because(cfg) is None
+    N, H, S = 70, 2, 40
+    cfg.ZeDO.OIL_iterations = S
+    d = syn.make_poses(N, seed=5, conf_mode="uniform")
+    cl = syn.make_clusters(H, seed=5)
+    sde = _driver.make_sde(cfg)
+    made = []
+    orig = sampling.get_sampling_fn
+    try:
+        sampling.get_sampling_fn = lambda *a, **k: made.append(orig(*a, **k)) or made[-1]
+        x_surface = _driver.stepwise_loop(cfg, model, sde, cl, d["db_2d"].copy(), d["camera_param"], S, torch.device("cuda"))
+    finally:
+        sampling.get_sampling_fn = orig
+    loop = made[0].loop_schedule
+    assert loop.hits == H * S and loop.misses == 0, (loop.hits, loop.misses)
+    pipe = Pipeline(weights0, ZeDOConfig.h36m(OIL_iterations=S), "cuda").load(cl, d["db_2d"], d["camera_param"])
+    x_fused, _ = pipe.run()
+    assert torch.equal(x_surface, x_fused)
+    # a caller stepping times of its own (not the loop's linspace) still gets the right step, via one-entry schedules
+    fn = orig(cfg, sde, (N, 17, 3), lambda v: v, cfg.ZeDO.sampling_eps, device=torch.device("cuda"))
+    x = x_fused[:N].clone()
+    _, a = fn(model, condition=None, denoise_x=x, t=torch.tensor(0.0377), t_step=3)
+    _, b = fn(model, condition=None, denoise_x=x, t=torch.tensor(0.0377), t_step=None)
+    assert np.array_equal(a, b) and fn.loop_schedule.misses == 2
+    for field, val in (("predictor", "reverse_diffusion"), ("corrector", "langevin")):
+        bad = _driver.load_config(cfg_path("h36m"))
+        setattr(bad.sampling, field, val)
+        assert field in _driver.not_fused_because(bad)
+    bad = _driver.load_config(cfg_path("h36m"))
+    bad.model.scale_by_sigma = True
+    assert "scale_by_sigma" in _driver.not_fused_because(bad)
+
+
+def _sha(*arrs):
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("name", ["driver_h36m_full", "driver_pw3d_full"])
+def test_fused_driver_at_baseline_size_matches_reference(weights0, golden, name):
+    """BASELINE configs[1] (H36M settings, N = 886, H = 1, S = 1000) and configs[2] (3DPW settings, N = 1015, H = 50,
+    S = 1000) at their STATED size against the reference's own run of run/opt_main.py:166-228 on identical inputs and
+    weights (tools/gen_golden.py::gen_driver_h36m_full / gen_driver_pw3d_full; the inputs are regenerated from the
+    committed seeds and checked against the fixture's hash).  Bar (BASELINE.json north_star): dataset-mean MPJPE and
+    PA-MPJPE within 0.05 mm.  The per-pose picture (argmin agreement, error deltas) goes to the parity report."""
+    import json
+    import zedo_hip
+    from zedo_hip.pipeline import Pipeline, ZeDOConfig
+    from lib.dataset import synthetic as syn
+    from lib.dataset.h36m import H36MDataset3D
+    from lib.dataset.pw3d import PW3D
+    g = golden(name)
+    N, H, S = int(g["N"]), int(g["H"]), int(g["S"])
+    h36m = str(g["dataset"]) == "h36m"
+    d = syn.make_poses(N, seed=int(g["seed_pose"]), conf_mode=str(g["conf_mode"]),
+                       dtype3d=np.float64 if h36m else np.float32)
+    cl = syn.make_clusters(H, seed=int(g["seed_cl"]))
+    assert _sha(d["db_2d"], d["camera_param"], cl) == str(g["inputs_sha"]), "inputs differ from the captured run"
+    cfg = ZeDOConfig(IPO_keylist=[int(k) for k in g["keylist"]], IPO_T=float(g["ipo_T"]),
+                     IPO_minScaleT=float(g["minT"]), OIL_iterations=S)
+    pipe = Pipeline(weights0, cfg, "cuda").load(cl, d["db_2d"], d["camera_param"])
+    x, T = pipe.run()
+    assert x.shape == (H * N, 17, 3) and bool(torch.isfinite(x).all())
+    if h36m:
+        ds = H36MDataset3D.from_arrays(d["db_2d"], d["db_3d"] * 1000.0, d["camera_param"], 2 + (np.arange(N) % 15))
+        gtc = (d["db_3d"] * 1000.0 - (d["db_3d"] * 1000.0)[:, 0:1]) / 1000.0
+    else:
+        ds = PW3D.from_arrays(d["db_2d"], d["db_3d"], d["camera_param"])
+        gtc = (d["db_3d"] - d["db_3d"][:, 0:1]).astype(np.float64)
+    p1 = ds.eval_multi(("rows", x), protocol2=False)
+    p2 = ds.eval_multi(("rows", x), protocol2=True)
+    rep = {"test": name, "N": N, "H": H, "S": S, "mpjpe_hip": p1, "mpjpe_ref": float(g["mpjpe"]), "pa_hip": p2,
+           "pa_ref": float(g["pa_mpjpe"]), "d_mpjpe_mm": abs(p1 - float(g["mpjpe"])) * 1e3,
+           "d_pa_mpjpe_mm": abs(p2 - float(g["pa_mpjpe"])) * 1e3}
+    gt = torch.as_tensor(gtc, device="cuda")
+    for key, proto in (("p1", False), ("p2", True)):
+        err, best, idx = zedo_hip.min_mpjpe(x, gt, N, procrustes=proto)
+        e = err.reshape(H, N).T.cpu().numpy()                  # [N, H]
+        db = best.cpu().numpy() - g[f"best_{key}"]
+        de = e - g[f"err_{key}"].astype(np.float64)
+        agree = float((idx.cpu().numpy() == g[f"argmin_{key}"]).mean())
+        rep[key] = dict(argmin_agreement=agree, best_delta_mm=dict(
+            mean=float(db.mean() * 1e3), abs_median=float(np.median(np.abs(db)) * 1e3),
+            abs_p90=float(np.percentile(np.abs(db), 90) * 1e3), abs_p99=float(np.percentile(np.abs(db), 99) * 1e3),
+            abs_max=float(np.abs(db).max() * 1e3)),
+            all_hypotheses_delta_mm=dict(mean=float(de.mean() * 1e3), abs_median=float(np.median(np.abs(de)) * 1e3),
+                                         abs_p99=float(np.percentile(np.abs(de), 99) * 1e3)))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_report.jsonl", "a") as f:
+        f.write(json.dumps(rep) + "\n")
+    print(json.dumps(rep))
+    assert rep["d_mpjpe_mm"] <= 0.05 and rep["d_pa_mpjpe_mm"] <= 0.05, rep
+
+
 def test_run_opt_main_and_inference_synthetic(tmp_path):
     import run.inference as inf
     import run.opt_main as om

@@ -177,16 +177,17 @@ def gen_reproj():
          x_far=xflip + np.array([0, 0, 12.0], np.float32), g_far=gF.numpy(), T_far=TF.numpy(), **out)
 
 
-def run_ref_ipo(x0, cond, K, axes, keylist, ipo_T, minT, maxT, iters, trace_upto=20):
-    """opt_main.py:170-195 on CPU tensors.  Returns dict of captures."""
-    denoise_x = torch.tensor(x0)
-    condition = torch.tensor(cond).float()
-    Kt = torch.tensor(K).float()
+def run_ref_ipo(x0, cond, K, axes, keylist, ipo_T, minT, maxT, iters, trace_upto=20, dtype=torch.float32):
+    """opt_main.py:170-195 on CPU tensors.  Returns dict of captures.  dtype=float64: the same statements with
+    every tensor and RotOpt().double() - the arbiter for the per-iteration IPO parity criterion."""
+    denoise_x = torch.tensor(x0).to(dtype)
+    condition = torch.tensor(cond).to(dtype)
+    Kt = torch.tensor(K).to(dtype)
     pelvis = torch.cat((condition[:, 0, :], torch.ones((condition.shape[0], 1))), axis=-1)
     T = torch.inverse(Kt).bmm(pelvis[:, :, None]).permute(0, 2, 1)
     T = T / torch.norm(T, dim=-1, keepdim=True) * ipo_T
     T0 = T.clone()
-    rot_opt = RotOpt(denoise_x.shape[0], axis=axes, minT=minT, maxT=maxT)
+    rot_opt = RotOpt(denoise_x.shape[0], axis=axes, minT=minT, maxT=maxT).to(dtype)
     opt = torch.optim.Adam(rot_opt.parameters(), lr=0.1)
     crit = torch.nn.L1Loss(reduction="none")
     tr_q, tr_s, tr_l = [], [], []
@@ -197,7 +198,7 @@ def run_ref_ipo(x0, cond, K, axes, keylist, ipo_T, minT, maxT, iters, trace_upto
         loss.backward()
         opt.step()
         if i < trace_upto:
-            z = torch.zeros(denoise_x.shape[0], 1)
+            z = torch.zeros(denoise_x.shape[0], 1, dtype=dtype)
             q = torch.cat([rot_opt.rot_vect] + [getattr(rot_opt, "rot_vect_%s" % a, z) for a in "xyz"], -1)
             tr_q.append(q.detach().numpy().copy())
             tr_s.append(rot_opt.scale.detach().numpy().reshape(-1).copy())
@@ -205,8 +206,12 @@ def run_ref_ipo(x0, cond, K, axes, keylist, ipo_T, minT, maxT, iters, trace_upto
     Tfin = (T * torch.clamp(rot_opt.scale, min=minT, max=maxT)).detach()
     R = rot_opt.generate_matrix().detach()
     return dict(T0=T0.numpy(), T=Tfin.numpy(), R=R.numpy(), loss=np.float32(float(loss)),
-                trace_q=np.stack(tr_q), trace_scale=np.stack(tr_s), trace_loss=np.array(tr_l, np.float32),
+                trace_q=np.stack(tr_q), trace_scale=np.stack(tr_s),
+                trace_loss=np.array(tr_l, np.float32 if dtype == torch.float32 else np.float64),
                 scale=rot_opt.scale.detach().numpy().reshape(-1))
+
+
+IPO_TRACE = 50
 
 
 def gen_ipo():
@@ -220,9 +225,16 @@ def gen_ipo():
         x0 = np.broadcast_to(centred[0][None], (N, 17, 3)).astype(np.float32).copy()
         for axes in ("z", "xyz"):
             for kname, kl, ipoT, minT in (("h36m", [0, 1, 4], 3.0, 0.5), ("pw3d", list(range(17)), 8.0, 0.2)):
-                r = run_ref_ipo(x0, d["db_2d"][:, :, :2], d["camera_param"], axes, kl, ipoT, minT, 2.0, 500)
+                r = run_ref_ipo(x0, d["db_2d"][:, :, :2], d["camera_param"], axes, kl, ipoT, minT, 2.0, 500,
+                                trace_upto=IPO_TRACE)
                 for k, v in r.items():
                     out[f"{k}_{N}_{axes}_{kname}"] = v
+                # fp64 arbiter (RotOpt().double(), every tensor double) for the per-iteration criterion
+                r64 = run_ref_ipo(x0, d["db_2d"][:, :, :2], d["camera_param"], axes, kl, ipoT, minT, 2.0, IPO_TRACE,
+                                  trace_upto=IPO_TRACE, dtype=torch.float64)
+                out[f"trace_q64_{N}_{axes}_{kname}"] = r64["trace_q"]
+                out[f"trace_scale64_{N}_{axes}_{kname}"] = r64["trace_scale"]
+                out[f"trace_loss64_{N}_{axes}_{kname}"] = r64["trace_loss"]
     save("ipo", cluster0=centred[0], **out)
 
 
@@ -320,6 +332,33 @@ def gen_eval():
             Z[n, h] = procrustes(gt.copy(), preds[n, h].copy())[1]
             e2[n, h] = np.mean(np.sqrt(np.square(Z[n, h] - gt).sum(axis=1)))
     out.update(err_p1=e1, err_p2=e2, aligned=Z)
+    # rank-2 alignments: the prediction, or the ground truth, lies in a plane, so A0^T B0 has a zero
+    # singular value and numpy's SVD returns an arbitrary sign for the null direction (transforms.py:88-96).
+    # Cases: plane z = 0 exactly (exact rank 2) and a random plane rounded to float32 (rank 2 to 1e-8).
+    gd = np.random.Generator(np.random.Philox(key=[7, 51]))
+
+    def flat(P, nrm):
+        nrm = nrm / np.linalg.norm(nrm)
+        return P - (P @ nrm)[..., None] * nrm
+
+    gen_gt = rel[:6].copy()                                                  # float64, general position
+    gen_pred = (rel[6:12] * 1.1 + 0.03 * gd.standard_normal((6, 17, 3))).astype(np.float32)
+    pl_pred = (rel[:6] + 0.03 * gd.standard_normal((6, 17, 3)))
+    pl_pred[:3, :, 2] = 0.0
+    pl_pred[3:] = flat(pl_pred[3:], gd.standard_normal(3))
+    pl_pred = pl_pred.astype(np.float32)
+    pl_gt = rel[6:12].copy()
+    pl_gt[:3, :, 2] = 0.0
+    pl_gt[3:] = flat(pl_gt[3:], gd.standard_normal(3))
+    deg = {}
+    for tag, G, P in (("planar_pred", gen_gt, pl_pred), ("planar_gt", pl_gt, gen_pred)):
+        e = np.zeros(6)
+        Zd = np.zeros((6, 17, 3))
+        for n in range(6):
+            Zd[n] = procrustes(G[n].copy(), P[n].copy())[1]
+            e[n] = np.mean(np.sqrt(np.square(Zd[n] - G[n]).sum(axis=1)))
+        deg[f"deg_{tag}_gt"], deg[f"deg_{tag}_pred"], deg[f"deg_{tag}_err_p2"], deg[f"deg_{tag}_aligned"] = G, P, e, Zd
+    out.update(deg)
     save("eval_multi", **out)
 
 
@@ -584,6 +623,23 @@ def write_3dhp_asset(N=45, seed=91):
         pickle.dump(items, f, protocol=4)
 
 
+def write_ski_asset(N=24, seed=93):
+    """ski_test.h5 with the dataset keys the reader parses (skiPose.py:119-157): per frame 3D [51] (metres,
+    camera frame), 2D [34] in 0..1 of the 256-pixel crop, cam_intrinsic [3,3] in crop units, seq / cam / frame.
+    Stored as an .npz archive under the .h5 name and served through tools/ref_stubs/h5py.py."""
+    d = syn.make_poses(N, seed=seed, dtype3d=np.float64)
+    K = d["camera_param"].astype(np.float64)
+    g = np.random.Generator(np.random.Philox(key=[seed, 7]))
+    cam = K / 256.0
+    cam[:, 2, 2] = 1.0 / 256.0 + 0.001 * g.standard_normal(N)       # the reader overwrites [2,2] with 1
+    os.makedirs(os.path.join(ASSETS, "ski"), exist_ok=True)
+    with open(os.path.join(ASSETS, "ski", "ski_test.h5"), "wb") as f:
+        np.savez_compressed(f, **{"3D": d["db_3d"].reshape(N, 51).astype(np.float32),
+                                  "2D": (d["db_2d"][:, :, :2].astype(np.float64) / 256.0).reshape(N, 34),
+                                  "cam_intrinsic": cam, "seq": (np.arange(N) % 3).astype(np.float64),
+                                  "cam": (np.arange(N) % 6).astype(np.int64), "frame": (7 * np.arange(N)).astype(np.int64)})
+
+
 def gen_3dhp_ski():
     import contextlib
     import io
@@ -624,7 +680,13 @@ def gen_3dhp_ski():
     out["pck_50_joints"] = np.float64(mutils.compute_PCK(a, b, eval_joints=[1, 2, 3, 14, 15, 16], threshold=50))
     out["auc"] = np.float64(mutils.compute_AUC(a, b))
     out["auc_joints"] = np.float64(mutils.compute_AUC(a, b, eval_joints=[0, 7, 8, 9, 10]))
-    # SkiPose eval_multi (reader needs h5py + the real asset)
+    # SkiPose reader (skiPose.py:119-157) through the h5py stand-in on a synthetic ski_test.h5
+    write_ski_asset()
+    for tag, kw in (("abs", dict(abs_coord=True)), ("rel_s5", dict(abs_coord=False, sample_interval=5))):
+        sds = skiPose(os.path.join(ASSETS, "ski"), "test", gt2d=True, flip=False, **kw)
+        out[f"skir_{tag}_db_2d"], out[f"skir_{tag}_db_3d"], out[f"skir_{tag}_camera_param"] = sds.db_2d, sds.db_3d, sds.camera_param
+        out[f"skir_{tag}_image_name"] = np.array([str(n) for n in sds.image_name])
+    # SkiPose eval_multi
     sk = object.__new__(skiPose)
     sk.db_3d = (ds.db_3d + 0.5).astype(np.float32)
     out["ski_db_3d"] = sk.db_3d
@@ -658,9 +720,96 @@ def gen_driver_full():
          batch_results=batch_results.astype(np.float32))
 
 
+def _driver_full_size(tag, N, H, S, seed_pose, seed_cl, keylist, ipo_T, minT, conf_mode, dataset, cache_dir):
+    """opt_main.py:166-228 at a BASELINE configuration's stated size.  One hypothesis at a time like the reference;
+    each finished hypothesis is parked under cache_dir so that an interrupted capture resumes.  Only small arrays
+    are committed: the per-(pose, hypothesis) errors, per-pose best / argmin, dataset means, the IPO outcome as
+    (rotation angle about z, depth scale) and the seeds of the inputs."""
+    w = syn.make_weights(seed=0)
+    m = ref_model(w)
+    d = syn.make_poses(N, seed=seed_pose, conf_mode=conf_mode, dtype3d=np.float64 if dataset == "h36m" else np.float32)
+    cl = syn.make_clusters(H, seed=seed_cl)
+    gt_2d, K = d["db_2d"], d["camera_param"]
+    os.makedirs(cache_dir, exist_ok=True)
+    batch_results, ang, scl, loss = [], [], [], []
+    import time
+    for sid in range(H):
+        f = os.path.join(cache_dir, f"{tag}_h{sid:02d}.npz")
+        if os.path.exists(f):
+            z = np.load(f)
+            res, R, Tf, T0, ls = z["res"], z["R"], z["T"], z["T0"], z["loss"]
+        else:
+            t0 = time.time()
+            noisy = torch.ones((N, 17, 3)) * torch.tensor(cl - cl[:, 0:1, :])[sid:sid + 1]
+            r = run_ref_ipo(noisy.numpy(), gt_2d[:, :, :2], K, "z", keylist, ipo_T, minT, 2.0, 500, trace_upto=1)
+            x = torch.tensor(r["R"]).bmm(noisy.permute(0, 2, 1)).permute(0, 2, 1).contiguous().numpy()
+            res, _, _ = run_ref_oil(m, x, gt_2d[:, :, :2], gt_2d[:, :, 2].copy(), K, r["T"], S, [])
+            R, Tf, T0, ls = r["R"], r["T"], r["T0"], r["loss"]
+            np.savez(f, res=res, R=R, T=Tf, T0=T0, loss=ls)
+            print(f"  {tag}: hypothesis {sid + 1}/{H} in {time.time() - t0:.0f} s", flush=True)
+        batch_results.append(res)
+        ang.append(np.arctan2(R[:, 1, 0], R[:, 0, 0]))
+        scl.append(Tf[:, 0, 2] / T0[:, 0, 2])
+        loss.append(ls)
+    batch_results = np.swapaxes(np.array(batch_results), 0, 1)           # [N, H, 17, 3]
+    if dataset == "h36m":
+        gt_mm = d["db_3d"] * 1000.0
+        actions = 2 + (np.arange(N) % 15)
+        ds = _h36m_obj(gt_mm, actions)
+        gtc = ((gt_mm - gt_mm[:, 0:1]) / 1000.0)
+    else:
+        ds = _pw3d_obj(d["db_3d"])
+        gtc = d["db_3d"] - d["db_3d"][:, 0:1]
+    p1 = ds.eval_multi(batch_results, protocol2=False)
+    p2 = ds.eval_multi(batch_results, protocol2=True)
+    # per (n, h) errors with the reference's own inner statements (h36m.py:402-408 / pw3d.py:318-326)
+    e1 = np.zeros((N, H))
+    e2 = np.zeros((N, H))
+    for n in range(N):
+        for h in range(H):
+            e1[n, h] = np.mean(np.sqrt(np.square(batch_results[n, h] - gtc[n]).sum(axis=1)))
+            Z = procrustes(gtc[n].copy(), batch_results[n, h].copy())[1]
+            e2[n, h] = np.mean(np.sqrt(np.square(Z - gtc[n]).sum(axis=1)))
+    save(tag, N=np.int64(N), H=np.int64(H), S=np.int64(S), seed_pose=np.int64(seed_pose), seed_cl=np.int64(seed_cl),
+         conf_mode=np.array(conf_mode), dataset=np.array(dataset), keylist=np.array(keylist), ipo_T=np.float64(ipo_T),
+         minT=np.float64(minT), mpjpe=np.float64(p1), pa_mpjpe=np.float64(p2),
+         err_p1=e1.astype(np.float32), err_p2=e2.astype(np.float32),
+         best_p1=e1.min(1), best_p2=e2.min(1), argmin_p1=e1.argmin(1).astype(np.int32), argmin_p2=e2.argmin(1).astype(np.int32),
+         ipo_angle=np.stack(ang).astype(np.float32), ipo_scale=np.stack(scl).astype(np.float32),
+         ipo_loss=np.array(loss, np.float32), inputs_sha=np.array(_sha(gt_2d, K, cl)))
+
+
+def _sha(*arrs):
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+CACHE = os.environ.get("ZEDO_GOLDEN_CACHE", "/tmp/zedo_golden_cache")
+
+
+def gen_driver_h36m_full():
+    """BASELINE configs[1] at its stated size: N = 886 (the H36M test set at ZeDO.sample = 640,
+    configs/optim/concat_pose_optimization_h36m.py:72-81), H = 1, S = 1000, key list [0,1,4], IPO_T 3,
+    H36MDataset3D.eval_multi (action-wise, millimetre float64 ground truth).  ~1 CPU-minute."""
+    _driver_full_size("driver_h36m_full", 886, 1, 1000, 101, 17, [0, 1, 4], 3.0, 0.5, "uniform", "h36m", CACHE)
+
+
+def gen_driver_pw3d_full():
+    """BASELINE configs[2] at its stated size: N = 1015, H = 50, S = 1000, 17-joint key list, IPO_T 8
+    (configs/optim/concat_pose_optimization_pw3d.py:72-81), PW3D.eval_multi.  ~45 CPU-minutes: run once
+    (python tools/gen_golden.py --only driver_pw3d_full); excluded from the default sweep."""
+    _driver_full_size("driver_pw3d_full", 1015, 50, 1000, 103, 19, list(range(17)), 8.0, 0.2, "uniform", "3dpw", CACHE)
+
+
+
 GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo, oil=gen_oil,
             eval=gen_eval, driver=gen_driver, datasets=gen_datasets,
-            driver_files=gen_driver_files, samplers=gen_samplers, pc_generic=gen_pc_generic, hp3d_ski=gen_3dhp_ski, driver_full=gen_driver_full)
+            driver_files=gen_driver_files, samplers=gen_samplers, pc_generic=gen_pc_generic, hp3d_ski=gen_3dhp_ski, driver_full=gen_driver_full,
+            driver_h36m_full=gen_driver_h36m_full, driver_pw3d_full=gen_driver_pw3d_full)
+SLOW = {"driver_pw3d_full"}     # only with --only
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -668,7 +817,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     for k, f in GENS.items():
-        if a.only in (None, k):
+        if a.only == k or (a.only is None and k not in SLOW):
             print("==", k)
             f()
     for p in [os.path.join(dp, f) for dp, _, fs in os.walk("/root/reference") for f in fs if f.endswith(".pyc")]:

@@ -1,11 +1,15 @@
 // C ABI of libzedo_hip.so (declared in include/zedo_hip.h): handle management, table building and the
-// launch sequences of the ZeDO hot path on gfx950.  No global state besides the opaque handles.
+// launch sequences of the ZeDO hot path on gfx950.
+// Process-wide state, all of it outside the data path: the sampled-timing diagnostic (g_prof, one profiling
+// session at a time, not thread safe), the ZEDO_CHUNK_ROWS value read once, and per-device launch attributes
+// cached in zedo_gemm.hip.  Everything a call computes with lives in the caller's buffers or the opaque handles.
 #include "../../include/zedo_hip.h"
 #include "zedo_internal.h"
 
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -22,6 +26,10 @@ struct zedo_weights {
     const float *W_s, *b_s;         // shared_time_embed.0
     const float *W_t[NLAYER];       // [H][E]  *_t.weight
     const float *b_sum[NLAYER];     // [H]     *_t.bias + dense.bias (both row-invariant)
+    // scratch of zedo_schedule_create for schedules of up to ROW_PAD timestamps (the per-step surface builds
+    // one-entry schedules): posemb [ROW_PAD][E] | temb [ROW_PAD][E] | t [ROW_PAD]; guarded by scratch_mu
+    float *d_scratch;
+    std::mutex scratch_mu;
 };
 
 struct zedo_schedule {
@@ -183,11 +191,13 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     zedo_weights *w = new (std::nothrow) zedo_weights();
     if (!w) return (int)hipErrorOutOfMemory;
     w->J3 = J3; w->hidden = hidden; w->embed = embed; w->n_blocks = n_blocks;
+    w->d_scratch = nullptr;
     hipError_t e = hipMalloc(&w->d_all, off * sizeof(float));
-    if (e != hipSuccess) { delete w; return (int)e; }
+    if (e == hipSuccess) e = hipMalloc(&w->d_scratch, sizeof(float) * ((size_t)2 * ROW_PAD * EMB + ROW_PAD));
+    if (e != hipSuccess) { (void)hipFree(w->d_all); delete w; return (int)e; }
     e = hipMemcpyAsync(w->d_all, img.data(), off * sizeof(float), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(w->d_all); delete w; return (int)e; }
+    if (e != hipSuccess) { (void)hipFree(w->d_all); (void)hipFree(w->d_scratch); delete w; return (int)e; }
     const float *d = w->d_all;
     w->W_pre = d + o_Wpre;
     for (int l = 0; l < 4; ++l) w->W_hid[l] = d + o_Whid0 + (size_t)l * H * H;
@@ -204,6 +214,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
 extern "C" void zedo_weights_destroy(zedo_weights_t *w) {
     if (!w) return;
     (void)hipFree(w->d_all);
+    (void)hipFree(w->d_scratch);
     delete w;
 }
 
@@ -226,11 +237,21 @@ extern "C" int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, i
         s->a[i] = (float)(1.0 + 0.5 * beta / n_sde);
         s->c[i] = (float)(-(beta * disc) / (n_sde * sd));
     }
+    // short schedules (the per-step surface asks for one timestamp at a time) borrow the scratch owned by the
+    // weights handle: no hipMalloc / hipFree of temporaries per call
+    const bool borrow = Sp == ROW_PAD;
+    std::unique_lock<std::mutex> lk(const_cast<zedo_weights_t *>(w)->scratch_mu, std::defer_lock);
     float *d_t = nullptr, *d_pe = nullptr, *d_temb = nullptr;
     s->d_tbias = nullptr;
-    hipError_t e = hipMalloc(&d_t, sizeof(float) * S);
-    if (e == hipSuccess) e = hipMalloc(&d_pe, sizeof(float) * (size_t)Sp * EMB);
-    if (e == hipSuccess) e = hipMalloc(&d_temb, sizeof(float) * (size_t)Sp * EMB);
+    hipError_t e = hipSuccess;
+    if (borrow) {
+        lk.lock();
+        d_pe = w->d_scratch; d_temb = d_pe + (size_t)ROW_PAD * EMB; d_t = d_temb + (size_t)ROW_PAD * EMB;
+    } else {
+        e = hipMalloc(&d_t, sizeof(float) * S);
+        if (e == hipSuccess) e = hipMalloc(&d_pe, sizeof(float) * (size_t)Sp * EMB);
+        if (e == hipSuccess) e = hipMalloc(&d_temb, sizeof(float) * (size_t)Sp * EMB);
+    }
     if (e == hipSuccess) e = hipMalloc(&s->d_tbias, sizeof(float) * (size_t)Sp * NLAYER * HID);
     if (e == hipSuccess) e = hipMemcpyAsync(d_t, h_t, sizeof(float) * S, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = launch_posemb(d_t, S, Sp, label_scale, d_pe, st);
@@ -247,8 +268,8 @@ extern "C" int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, i
         a.out = s->d_tbias + (size_t)l * HID; a.ldo = NLAYER * HID; a.K = EMB; a.N = HID; a.Mp = Sp;
         e = launch_layer(a, EPI_BIAS, st);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d_t); (void)hipFree(d_pe); (void)hipFree(d_temb);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);      // h_t may be freed by the caller; the scratch is released
+    if (!borrow) { (void)hipFree(d_t); (void)hipFree(d_pe); (void)hipFree(d_temb); }
     if (e != hipSuccess) { (void)hipFree(s->d_tbias); delete s; return (int)e; }
     *out = s;
     return ZEDO_OK;
@@ -386,13 +407,15 @@ extern "C" int zedo_oil_run(const zedo_weights_t *w, const zedo_schedule_t *s, f
     return ZEDO_OK;
 }
 
-extern "C" int zedo_ipo_fit(const float *d_x0, const float *d_uv, const float *d_K, const int *h_keylist, int k,
-                            int axes_mask, float ipo_T, float min_scale, float max_scale, int iters, double normaliser,
-                            float *d_R, float *d_T, float *d_q, float *d_scale, int B, int N, int J, long long row_offset,
-                            void *stream) {
-    if (!d_x0 || !d_uv || !d_K || !h_keylist || !d_R || !d_T || B < 1 || N < 1 || J < 1 || k < 1 || k > 17 ||
-        iters < 0 || !(normaliser > 0) || row_offset < 0)
+extern "C" int zedo_ipo_fit_resume(const float *d_x0, const float *d_uv, const float *d_K, const int *h_keylist, int k,
+                                   int axes_mask, float ipo_T, float min_scale, float max_scale, int iters,
+                                   double normaliser, float *d_R, float *d_T, float *d_q, float *d_scale,
+                                   float *d_state, int it_begin, int B, int H, int N, int J, long long row_offset,
+                                   void *stream) {
+    if (!d_x0 || !d_uv || !d_K || !h_keylist || !d_R || !d_T || B < 1 || H < 1 || N < 1 || J < 1 || k < 1 || k > 17 ||
+        iters < 0 || it_begin < 0 || (it_begin > 0 && !d_state) || !(normaliser > 0) || row_offset < 0)
         return ZEDO_E_BADARG;
+    if (row_offset + (long long)B > (long long)H * N) return ZEDO_E_BADARG;   // x0[h] would be read out of bounds
     for (int i = 0; i < k; ++i)
         if (h_keylist[i] < 0 || h_keylist[i] >= J) return ZEDO_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -401,15 +424,24 @@ extern "C" int zedo_ipo_fit(const float *d_x0, const float *d_uv, const float *d
     hipError_t e = hipMemcpyAsync(d_kl, h_keylist, sizeof(int) * k, hipMemcpyHostToDevice, st);
     if (e == hipSuccess)
         e = launch_ipo_fit(d_x0, d_uv, d_K, d_kl, k, axes_mask, ipo_T, min_scale, max_scale, iters, normaliser, d_R, d_T,
-                           d_q, d_scale, B, N, J, row_offset, st);
+                           d_q, d_scale, d_state, it_begin, B, N, J, row_offset, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);  // d_kl is freed below; h_keylist may be pageable
     (void)hipFree(d_kl);
     return (int)e;
 }
 
-extern "C" int zedo_rotate_init(const float *d_x0, const float *d_R, float *d_x, int B, int N, int J, long long row_offset,
-                                void *stream) {
-    if (!d_x0 || !d_R || !d_x || B < 1 || N < 1 || J < 1 || row_offset < 0) return ZEDO_E_BADARG;
+extern "C" int zedo_ipo_fit(const float *d_x0, const float *d_uv, const float *d_K, const int *h_keylist, int k,
+                            int axes_mask, float ipo_T, float min_scale, float max_scale, int iters, double normaliser,
+                            float *d_R, float *d_T, float *d_q, float *d_scale, int B, int H, int N, int J,
+                            long long row_offset, void *stream) {
+    return zedo_ipo_fit_resume(d_x0, d_uv, d_K, h_keylist, k, axes_mask, ipo_T, min_scale, max_scale, iters, normaliser,
+                               d_R, d_T, d_q, d_scale, nullptr, 0, B, H, N, J, row_offset, stream);
+}
+
+extern "C" int zedo_rotate_init(const float *d_x0, const float *d_R, float *d_x, int B, int H, int N, int J,
+                                long long row_offset, void *stream) {
+    if (!d_x0 || !d_R || !d_x || B < 1 || H < 1 || N < 1 || J < 1 || row_offset < 0) return ZEDO_E_BADARG;
+    if (row_offset + (long long)B > (long long)H * N) return ZEDO_E_BADARG;
     HIPCHK(launch_rotate_init(d_x0, d_R, d_x, B, N, J, row_offset, (hipStream_t)stream));
     return ZEDO_OK;
 }

@@ -52,6 +52,7 @@
 //     ~45 % of the time (tools/ubench/timeline_stats.py).
 #include "zedo_internal.h"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace zedo {
@@ -86,9 +87,12 @@ template <int EPI>
 __device__ __forceinline__ void epilogue_values(const f32x16 &acc, const f32x4 (&b4)[4], const f32x4 (&ga)[4],
                                                 const f32x4 (&be)[4], float sde_c, float (&o)[16]) {
     if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
-        // Same arithmetic as the scalar form below, written on float pairs so that it maps to v_pk_add / v_pk_mul /
-        // v_pk_fma_f32 (two results per VALU issue slot): VALU issue time is matrix-pipe time for the co-resident
-        // workgroup, and this epilogue is the largest non-MFMA item of the layer.
+        // GroupNorm(32 groups of 32 channels, biased variance, eps 1e-5: model.py:116,145,150) then SiLU:
+        //   o = acc + bias;  mean = sum32(o)/32;  o -= mean;  rstd = rsq(sum32(o^2)/32 + 1e-5);
+        //   y = o * (rstd * gamma) + beta;  out = y / (1 + exp(-y))
+        // written on float pairs so that it maps to v_pk_add / v_pk_mul / v_pk_fma_f32 (two results per VALU issue
+        // slot): VALU issue time is matrix-pipe time for the co-resident workgroup, and this epilogue is the largest
+        // non-MFMA item of the layer.
         f32x2 p[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -131,26 +135,7 @@ __device__ __forceinline__ void epilogue_values(const f32x16 &acc, const f32x4 (
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[4 * g + e] = acc[4 * g + e] + b4[g][e];
-    if constexpr (EPI == 99) {     // scalar statement of the GroupNorm + SiLU epilogue (kept as documentation of the packed form above)
-        // GroupNorm(32 groups of 32 channels), biased variance, eps 1e-5 (model.py:116,145,150), then SiLU
-        float s = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s += o[e];
-        s += __shfl_xor(s, 32);
-        const float mean = s * (1.0f / 32.0f);
-        float qs = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            o[e] -= mean;
-            qs += o[e] * o[e];
-        }
-        qs += __shfl_xor(qs, 32);
-        const float rstd = __builtin_amdgcn_rsqf(qs * (1.0f / 32.0f) + 1e-5f);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[4 * g + e] = silu_fast(o[4 * g + e] * (rstd * ga[g][e]) + be[g][e]);
-    } else if constexpr (EPI == EPI_SDE) {            // x' = a x + c eps  (sampling.py:185-190 folded)
+    if constexpr (EPI == EPI_SDE) {            // x' = a x + c eps  (sampling.py:185-190 folded)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[e] *= sde_c;
     } else if constexpr (EPI == EPI_BIAS_SILU) {      // built once per schedule: IEEE exp / divide
@@ -519,18 +504,33 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : ZEDO_PLAIN_WPE) void layer
     }
 }
 
+// Per-device launch state.  The dense kernels ask for 67-83 KB of dynamic LDS (above the 64 KB default), which must
+// be allowed once per kernel AND per device; the flags are idempotent (a race sets the attribute twice).
+constexpr int MAX_DEVICES = 16;
+static int current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return (dev >= 0 && dev < MAX_DEVICES) ? dev : 0;
+}
+static hipError_t allow_lds(const void *kern, size_t lds, std::atomic<bool> *done) {
+    const int dev = current_device();
+    if (!done[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done[dev].store(true, std::memory_order_release);
+    }
+    return hipSuccess;
+}
+static int num_cus();
+
 template <int EPI, int W8>
 static hipError_t launch_pair(const LayerArgs &big, const LayerArgs &small, hipStream_t st) {
     constexpr int SM = W8 ? 64 : 32;                                                    // remainder tile rows
     constexpr size_t lds = ((size_t)2 * (128 + 128) * 32 + 3 * 128) * sizeof(float);   // the big shape's need covers the small one's
     if (big.Mp % 128 || small.Mp % SM || big.N % 128 || big.K % 64) return hipErrorInvalidValue;
     auto kern = layer_pair_kernel<EPI, W8>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<bool> attr_done[MAX_DEVICES];      // per instantiation and per device
+    if (hipError_t e = allow_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const int nbig = (big.Mp / 128) * (big.N / 128), nsmall = (small.Mp / SM) * (small.N / 128);
     hipLaunchKernelGGL(kern, dim3(nbig + nsmall), dim3(W8 ? 512 : 256), lds, st, big, small, nbig);
     return hipGetLastError();
@@ -541,26 +541,23 @@ static hipError_t launch_cfg(const LayerArgs &a, hipStream_t st) {
     constexpr size_t lds = ((size_t)NBUF * (BM + BN) * BK + 3 * BN) * sizeof(float);
     if (a.Mp <= 0 || a.Mp % BM || a.N % BN || a.K % (BK * NBUF)) return hipErrorInvalidValue;
     auto kern = layer_kernel<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, WPE>;
-    static bool attr_done = false;  // per instantiation; benign race (idempotent call)
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<bool> attr_done[MAX_DEVICES];      // per instantiation and per device
+    if (hipError_t e = allow_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const int nwg = (a.Mp / BM) * (a.N / BN);
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(WM * WN * 64), lds, st, a);
     return hipGetLastError();
 }
 
 static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
+    static std::atomic<int> n[MAX_DEVICES];
+    const int dev = current_device();
+    int v = n[dev].load(std::memory_order_relaxed);
+    if (!v) {
         hipDeviceProp_t p;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+        v = (hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+        n[dev].store(v, std::memory_order_relaxed);
     }
-    return n;
+    return v;
 }
 
 static LayerArgs rows_of(const LayerArgs &a, int row0, int rows) {

@@ -284,7 +284,8 @@ __global__ __launch_bounds__(IPO_TB) void ipo_kernel(const float *__restrict__ x
                                                      int k, int axes_mask, float ipo_T, float min_s, float max_s,
                                                      int iters, float inv_norm, float *__restrict__ Rout,
                                                      float *__restrict__ Tout, float *__restrict__ qout,
-                                                     float *__restrict__ sout, int B, int N, int J,
+                                                     float *__restrict__ sout, float *__restrict__ state,
+                                                     int it_begin, double b1p0, double b2p0, int B, int N, int J,
                                                      long long row_offset) {
     __shared__ float s_cu[IPO_KMAX][IPO_TB], s_cv[IPO_KMAX][IPO_TB];
     __shared__ int s_kl[IPO_KMAX];
@@ -316,7 +317,14 @@ __global__ __launch_bounds__(IPO_TB) void ipo_kernel(const float *__restrict__ x
     }
     AdamP qr{1.f, 0.f, 0.f}, qi{0.f, 0.f, 0.f}, qj{0.f, 0.f, 0.f}, qk{0.f, 0.f, 0.f}, sc{1.f, 0.f, 0.f};
     const bool ax = axes_mask & 1, ay = axes_mask & 2, az = axes_mask & 4;
-    double b1p = 1.0, b2p = 1.0;
+    // resumable fit: state[b] = (p[5], exp_avg[5], exp_avg_sq[5]) in the order (rot_vect, x, y, z, scale) after
+    // it_begin iterations; b1p0 / b2p0 = beta^it_begin.  it_begin == 0 starts from RotOpt's initial values.
+    float *stp = state ? state + (size_t)b * 15 : nullptr;
+    if (stp && it_begin > 0) {
+        qr = AdamP{stp[0], stp[5], stp[10]}; qi = AdamP{stp[1], stp[6], stp[11]}; qj = AdamP{stp[2], stp[7], stp[12]};
+        qk = AdamP{stp[3], stp[8], stp[13]}; sc = AdamP{stp[4], stp[9], stp[14]};
+    }
+    double b1p = b1p0, b2p = b2p0;
     for (int it = 0; it < iters; ++it) {
         const float r = qr.p, i = qi.p, j = qj.p, kk = qk.p;
         const float n2 = r * r + i * i + j * j + kk * kk;
@@ -379,17 +387,24 @@ __global__ __launch_bounds__(IPO_TB) void ipo_kernel(const float *__restrict__ x
         Tout[(size_t)b * 3] = T0[0] * scc; Tout[(size_t)b * 3 + 1] = T0[1] * scc; Tout[(size_t)b * 3 + 2] = T0[2] * scc;
         if (qout) { qout[(size_t)b * 4] = r; qout[(size_t)b * 4 + 1] = i; qout[(size_t)b * 4 + 2] = j; qout[(size_t)b * 4 + 3] = kk; }
         if (sout) sout[b] = sc.p;
+        if (stp) {
+            const AdamP *all[5] = {&qr, &qi, &qj, &qk, &sc};
+#pragma unroll
+            for (int c = 0; c < 5; ++c) { stp[c] = all[c]->p; stp[5 + c] = all[c]->m; stp[10 + c] = all[c]->v; }
+        }
     }
 }
 
 hipError_t launch_ipo_fit(const float *x0, const float *uv, const float *K, const int *d_keylist, int k,
                           int axes_mask, float ipo_T, float min_scale, float max_scale, int iters,
-                          double normaliser, float *R, float *T, float *q, float *scale, int B, int N, int J,
-                          long long row_offset, hipStream_t st) {
+                          double normaliser, float *R, float *T, float *q, float *scale, float *state, int it_begin,
+                          int B, int N, int J, long long row_offset, hipStream_t st) {
     if (k < 1 || k > IPO_KMAX) return hipErrorInvalidValue;
+    double b1p0 = 1.0, b2p0 = 1.0;
+    for (int i = 0; i < it_begin; ++i) { b1p0 *= 0.9; b2p0 *= 0.999; }   // the same running products the kernel forms
     hipLaunchKernelGGL(ipo_kernel, dim3((B + IPO_TB - 1) / IPO_TB), dim3(IPO_TB), 0, st, x0, uv, K, d_keylist, k,
-                       axes_mask, ipo_T, min_scale, max_scale, iters, (float)(1.0 / normaliser), R, T, q, scale, B, N,
-                       J, row_offset);
+                       axes_mask, ipo_T, min_scale, max_scale, iters, (float)(1.0 / normaliser), R, T, q, scale, state,
+                       it_begin, b1p0, b2p0, B, N, J, row_offset);
     return hipGetLastError();
 }
 

@@ -108,6 +108,16 @@ __global__ void row_error_kernel(const float *__restrict__ pred, const double *_
     err[b] = e / J;
 }
 
+// np.amin / np.argmin order: NaN is smaller than everything (a diverged hypothesis poisons the pose, and the first
+// NaN index is reported), otherwise the smaller value, ties to the lower hypothesis index.
+__device__ __forceinline__ bool min_takes(double ov, int oh, double v, int h) {
+    if (oh < 0) return false;
+    if (h < 0) return true;
+    const bool on = ov != ov, vn = v != v;
+    if (on || vn) return on && (!vn || oh < h);
+    return ov < v || (ov == v && oh < h);
+}
+
 // one wavefront per pose: min / first arg-min (np.argmin tie rule) over the hypotheses held locally
 __global__ void pose_min_kernel(const double *__restrict__ err, int B, int N, long long row_offset,
                                 double *__restrict__ best, int *__restrict__ best_h) {
@@ -123,14 +133,13 @@ __global__ void pose_min_kernel(const double *__restrict__ err, int B, int N, lo
         const long long loc = h * N + n - row_offset;
         if (loc >= B) break;
         const double v = err[loc];
-        if (hi < 0 || v < e) { e = v; hi = (int)h; }
+        if (min_takes(v, (int)h, e, hi)) { e = v; hi = (int)h; }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const double oe = __shfl_xor(e, off);
         const int oh = __shfl_xor(hi, off);
-        const bool take = (oh >= 0) && (hi < 0 || oe < e || (oe == e && oh < hi));
-        if (take) { e = oe; hi = oh; }
+        if (min_takes(oe, oh, e, hi)) { e = oe; hi = oh; }
     }
     if (lane == 0) { best[n] = (hi >= 0) ? e : __builtin_huge_val(); best_h[n] = hi; }
 }

@@ -58,10 +58,19 @@ class ScoreModelFC_Adv(nn.Module):
         self.post_dense = nn.Linear(hidden_dim, d)
         self._packed = None          # (version key, zedo_hip.Weights)
         self._sched_cache = {}
+        self._plist = None           # the parameter tensors, walked once (Module.parameters() costs ~0.3 ms per walk)
 
     # ---- device-side copy of the parameters --------------------------------------------------------
+    def _apply(self, fn, *a, **k):   # .to() / .cuda() / .float(): parameter storage may move
+        self._plist = None
+        return super()._apply(fn, *a, **k)
+
     def _version(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """Cheap fingerprint of the parameter values: storage address + in-place version counter of each tensor
+        (load_state_dict, optimiser steps and .copy_ bump the counter)."""
+        if self._plist is None:
+            self._plist = list(self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in self._plist)
 
     def hip_weights(self):
         import zedo_hip

@@ -61,6 +61,25 @@ def perpendicular_distance(point, vector):
     return torch.sum(point * vector, dim=-1, keepdim=True) * vector - point
 
 
+_geom_cache = {}      # one entry: the step-invariant rays of the tensors the loop passes again and again
+
+
+def _rays(uv, Kc, cc):
+    """zedo_reproj_prepare for (key2d, K, conf), reused while the SAME tensor objects come back unmodified
+    (torch's version counters): the reference's loop hands gradient_field_gen identical condition / K / conf
+    tensors 1000 times per hypothesis (run/opt_main.py:203-206).  conf is clamped in place on every build, as
+    the reference does on every call (:64-66; idempotent)."""
+    import zedo_hip
+    key = tuple((id(a), a.data_ptr(), a._version, tuple(a.shape)) if a is not None else None for a in (uv, Kc, cc))
+    hit = _geom_cache.get("entry")
+    if hit is not None and hit[0] == key:
+        return hit[2]
+    geom = zedo_hip.reproj_prepare(uv, Kc, cc, cc)
+    key = tuple((id(a), a.data_ptr(), a._version, tuple(a.shape)) if a is not None else None for a in (uv, Kc, cc))
+    _geom_cache["entry"] = (key, (uv, Kc, cc), geom)          # the tensors are held so that ids stay unique
+    return geom
+
+
 def gradient_field_gen(key2d, key3d, K, noise_type=None, t=None, conf=None, returnT=False, norm_true=None,
                        previous_T=None):
     """Gradient of the 3D keypoints towards their camera rays (reference :46-125).
@@ -76,13 +95,13 @@ def gradient_field_gen(key2d, key3d, K, noise_type=None, t=None, conf=None, retu
     Kc = K.float().contiguous()
     if conf is not None:
         cc = conf if (conf.is_contiguous() and conf.dtype == torch.float32) else conf.float().contiguous()
-        geom = zedo_hip.reproj_prepare(uv, Kc, cc, cc)
+        geom = _rays(uv, Kc, cc)
         if cc is not conf:
             conf.copy_(cc)
     else:
-        geom = zedo_hip.reproj_prepare(uv, Kc, None, None)
+        geom = _rays(uv, Kc, None)
     if t is None:
-        T = torch.zeros((B, 3), dtype=torch.float32, device=x.device)
+        T = torch.empty((B, 3), dtype=torch.float32, device=x.device)      # written by the kernel (solve_T)
         g = zedo_hip.reproj_grad(x, geom, T, True)
     else:
         T = t.reshape(B, 3).float().contiguous().clone()

@@ -12,7 +12,7 @@ import pickle
 
 import numpy as np
 
-from ._eval import hypothesis_min, print_table
+from ._eval import hypothesis_min, print_table, subsample
 
 
 class H36MDataset3D:
@@ -99,8 +99,7 @@ class H36MDataset3D:
         ("rows", cuda tensor [H*N,17,3]) to keep the sampler output on the device."""
         print("eval multi-hypothesis...")
         gt = self.gt_centred()
-        if sample_interval is not None and not isinstance(preds, tuple):
-            preds = preds[::sample_interval]
+        preds, gt = subsample(preds, gt, sample_interval)
         best, idx = hypothesis_min(preds, gt, protocol2, valid_ind, row_offset)
         k = int(np.argmin(best))
         print(f"maximum MPJPE error: {min(best[k], 1000)} and it is at index: {k}, {idx[k]}")

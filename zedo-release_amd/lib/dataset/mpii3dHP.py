@@ -13,7 +13,7 @@ import pickle
 
 import numpy as np
 
-from ._eval import hypothesis_min, print_table
+from ._eval import hypothesis_min, print_table, subsample
 
 ACTION_CONVERTOR = [15, 17, 10, 18, 19, 20, 21]
 ACTIONS = [15, 10, 17, 18, 19, 20, 21]          # table order of the reference (:501)
@@ -95,9 +95,8 @@ class MPII3DHP:
         PCK / AUC need the predictions themselves: pass `preds` as [N,H,17,3] or ("rows", tensor) holding ALL rows."""
         from lib.algorithms.advanced.utils import compute_AUC, compute_PCK
         print("eval multi-hypothesis...")
-        if sample_interval is not None and not isinstance(preds, tuple):
-            preds = preds[::sample_interval]
-        best, idx = hypothesis_min(preds, self.gt_centred(), protocol2, valid_ind, row_offset)
+        preds, gt = subsample(preds, self.gt_centred(), sample_interval)
+        best, idx = hypothesis_min(preds, gt, protocol2, valid_ind, row_offset)
         N = len(best)
         if isinstance(preds, tuple):
             rows = preds[1]

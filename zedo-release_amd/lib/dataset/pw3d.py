@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from ._eval import hypothesis_min
+from ._eval import hypothesis_min, subsample
 
 ORDER = [5, 2, 6, 3, 11, 14, 12, 15, 13, 16, 1, 4, 8, 10, 0, 7, 9]
 
@@ -75,9 +75,8 @@ class PW3D:
     def eval_multi(self, preds, protocol2=False, print_verbose=False, sample_interval=None, valid_ind=None, joint=17, row_offset=0):
         """Best-of-H mean (PA-)MPJPE over poses (reference :286-345)."""
         print("eval multi-hypothesis...")
-        if sample_interval is not None and not isinstance(preds, tuple):
-            preds = preds[::sample_interval]
-        best, idx = hypothesis_min(preds, self.gt_centred(), protocol2, valid_ind, row_offset)
+        preds, gt = subsample(preds, self.gt_centred(), sample_interval)
+        best, idx = hypothesis_min(preds, gt, protocol2, valid_ind, row_offset)
         error = float(np.mean(best))
         print(f"mean PA-MPJPE : {error}" if protocol2 else f"mean MPJPE : {error}")
         self.last_best, self.last_index = best, idx

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from ._eval import hypothesis_min
+from ._eval import hypothesis_min, subsample
 
 
 class skiPose:
@@ -67,9 +67,8 @@ class skiPose:
     def eval_multi(self, preds, protocol2=False, print_verbose=False, sample_interval=None, valid_ind=None, row_offset=0):
         """Best-of-H mean (PA-)MPJPE over poses (reference :159-205)."""
         print("eval multi-hypothesis...")
-        if sample_interval is not None and not isinstance(preds, tuple):
-            preds = preds[::sample_interval]
-        best, idx = hypothesis_min(preds, self.gt_centred(), protocol2, valid_ind, row_offset)
+        preds, gt = subsample(preds, self.gt_centred(), sample_interval)
+        best, idx = hypothesis_min(preds, gt, protocol2, valid_ind, row_offset)
         error = float(np.mean(best))
         print(f"mean PA-MPJPE : {error}" if protocol2 else f"mean MPJPE : {error}")
         self.last_best, self.last_index = best, idx

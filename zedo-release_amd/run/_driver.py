@@ -89,11 +89,78 @@ def make_dataset(config, args, inference):
     raise NotImplementedError(f"dataset '{ds}' is outside the ported path (SURVEY.md 2, rows 14-15: infant pipeline)")
 
 
+def make_sde(config):
+    """run/opt_main.py:139-150"""
+    from lib.algorithms.advanced import sde_lib
+    name, m = config.training.sde.lower(), config.model
+    if name == "vpsde":
+        return sde_lib.VPSDE(beta_min=m.beta_min, beta_max=m.beta_max, N=m.num_scales, T=m.t)
+    if name == "subvpsde":
+        return sde_lib.subVPSDE(beta_min=m.beta_min, beta_max=m.beta_max, N=m.num_scales, T=m.t)
+    if name == "vesde":
+        return sde_lib.VESDE(sigma_min=m.sigma_min, sigma_max=m.sigma_max, N=m.num_scales, T=m.t)
+    raise NotImplementedError(f"SDE {config.training.sde} unknown.")
+
+
+def not_fused_because(config):
+    """The fused pipeline (zedo_oil_run) is the closed form x' = a_i x + c_i eps(x, 999 t_i) of ONE sampler
+    configuration - the one every shipped configs/optim/*.py selects (sampling.py:80-127 + run/opt_main.py:157).
+    Returns None when `config` is that configuration, else the first field that differs: the driver then steps
+    the reference's loop through get_sampling_fn, which implements the other SDEs / update rules, instead of
+    silently running a different algorithm."""
+    s, t, m = config.sampling, config.training, config.model
+    checks = (("training.sde", t.sde.lower(), "subvpsde"), ("sampling.method", s.method.lower(), "pc"),
+              ("sampling.predictor", s.predictor.lower(), "euler_maruyama"),
+              ("sampling.corrector", s.corrector.lower(), "none"), ("training.continuous", bool(t.continuous), True),
+              ("model.scale_by_sigma", bool(m.scale_by_sigma), False),
+              ("sampling.noise_removal", bool(s.noise_removal), True))
+    for name, got, want in checks:
+        if got != want:
+            return f"{name} = {got!r}, fused path: {want!r}"
+    return None
+
+
+def stepwise_loop(config, model, sde, sample_poses, gt_2d, K, S, device):
+    """run/opt_main.py:166-222 as written there - one hypothesis at a time, IPO through RotOpt (one zedo_ipo_fit
+    launch), then S iterations of gradient_field_gen + sampling_fn with the host round trip the reference's
+    pc_sampler makes - for configurations outside the fused pipeline.  Returns rows [H*N,17,3] (h-major)."""
+    from lib.algorithms.advanced import sampling
+    from lib.algorithms.advanced.simple_zeroshot_opt import RotOpt, gradient_field_gen
+    z = config.ZeDO
+    N = len(gt_2d)
+    sampling_fn = sampling.get_sampling_fn(config, sde, (N, N_JOINTS, JOINT_DIM), lambda v: v, z.sampling_eps,
+                                           device=device)
+    condition = torch.tensor(gt_2d[:, :, :2], device=device).float()
+    conf = torch.tensor(gt_2d[:, :, 2], device=device).float()
+    Kd = torch.tensor(K, device=device).float()
+    centred = torch.tensor(sample_poses - sample_poses[:, 0:1, :], device=device).float()
+    timestamp = torch.linspace(sde.T, z.sampling_eps, S, device=device)
+    out = []
+    for sid in range(len(sample_poses)):
+        x0 = centred[sid:sid + 1]
+        rot_opt = RotOpt(N, axis=z.RotAxes, minT=z.IPO_minScaleT, maxT=z.IPO_maxScaleT).to(device)
+        R, T = rot_opt.fit(x0, condition, Kd, z.IPO_keylist, z.IPO_T, z.IPO_iterations)
+        with torch.no_grad():
+            import zedo_hip
+            denoise_x = zedo_hip.rotate_init(x0.contiguous(), R.contiguous(), N)      # rot_mat.bmm(x^T)^T, :201
+            for i in range(S):
+                if i < S // 5:
+                    g = gradient_field_gen(condition, denoise_x, Kd, t=T, conf=conf, returnT=False)
+                else:
+                    g, T = gradient_field_gen(condition, denoise_x, Kd, conf=conf, returnT=True)
+                denoise_x += g
+                _, results = sampling_fn(model, condition=condition * 0, gradient=g, denoise_x=denoise_x,
+                                         t=timestamp[i], t_step=i, args=None)
+                denoise_x = torch.as_tensor(results).to(device)
+        out.append(denoise_x)
+    return torch.cat(out, 0).contiguous()
+
+
 def run(args, inference=False):
     from lib.algorithms.advanced import sde_lib
     from lib.algorithms.advanced.model import ScoreModelFC_Adv
     from lib.algorithms.ema import ExponentialMovingAverage
-    from zedo_hip.pipeline import Pipeline, ZeDOConfig, shard_rows
+    from zedo_hip.pipeline import Pipeline, ZeDOConfig, force_dist, gather_row_shards, shard_rows
 
     config = load_config(args.config)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,10 +168,12 @@ def run(args, inference=False):
         raise SystemExit("this driver needs an MI355X: the sampling path has no CPU fallback")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     device = torch.device("cuda", torch.cuda.current_device())
-    if world > 1:
+    use_dist = world > 1 or force_dist()      # ZEDO_FORCE_DIST=1: the RCCL path with one rank (tests)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
 
     if args.synthetic:
         from lib.dataset import synthetic as syn
@@ -133,30 +202,29 @@ def run(args, inference=False):
         print(f"=> loaded checkpoint '{ckpt_path}' (step {ckpt['step']})")
     model.eval()
 
-    name = config.training.sde.lower()
-    if name != "subvpsde":
-        raise NotImplementedError(f"SDE '{name}': the fused pipeline implements the sub-VP SDE of the shipped configs")
-    sde = sde_lib.subVPSDE(beta_min=config.model.beta_min, beta_max=config.model.beta_max,
-                           N=config.model.num_scales, T=config.model.t)
-    config.sampling.probability_flow = True
+    config.sampling.probability_flow = True                       # run/opt_main.py:157
     assert config.ZeDO.batch == len(gt_3d), f"batch: {config.ZeDO.batch}, dataset len: {len(gt_3d)}"
-
+    sde = make_sde(config)
     z = config.ZeDO
     S = args.oil_iterations or z.OIL_iterations
-    cfg = ZeDOConfig(z.IPO_iterations, z.IPO_keylist, z.RotAxes, z.IPO_T, z.IPO_minScaleT, z.IPO_maxScaleT, S,
-                     z.sampling_eps, sde.T, sde.N, sde.beta_0, sde.beta_1)
-    pipe = Pipeline(model.hip_weights(), cfg, device).load(sample_poses, gt_2d, K)
-    H, N = pipe.H, pipe.N
+    H, N = len(sample_poses), len(gt_3d)
     lo, rows = shard_rows(H * N, rank, world)
-    x, T = pipe.run(row_offset=lo, rows=rows)
+    why = not_fused_because(config)
+    if why is None:
+        cfg = ZeDOConfig(z.IPO_iterations, z.IPO_keylist, z.RotAxes, z.IPO_T, z.IPO_minScaleT, z.IPO_maxScaleT, S,
+                         z.sampling_eps, sde.T, sde.N, sde.beta_0, sde.beta_1)
+        pipe = Pipeline(model.hip_weights(), cfg, device).load(sample_poses, gt_2d, K)
+        x, T = pipe.run(row_offset=lo, rows=rows)
+    else:
+        if use_dist and world > 1:
+            raise NotImplementedError(f"multi-GPU runs use the fused pipeline, which this configuration leaves ({why})")
+        print(f"configuration outside the fused pipeline ({why}): stepping the loop of run/opt_main.py:166-222 "
+              "through the per-step sampling_fn surface")
+        x = stepwise_loop(config, model, sde, sample_poses, gt_2d, K, S, device)
 
     batch_results = None
     if inference:          # results.npy holds every hypothesis: [N, H, 17, 3] (run/inference.py:233-236)
-        full = torch.zeros((H * N, N_JOINTS, JOINT_DIM), dtype=torch.float32, device=device)
-        full[lo:lo + rows] = x
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(full)          # disjoint shards: a sum is a gather
+        full = gather_row_shards(x, H * N)            # one RCCL all-gather of the row shards
         batch_results = full.reshape(H, N, N_JOINTS, JOINT_DIM).permute(1, 0, 2, 3).cpu().numpy()
         if rank == 0:
             np.save(args.out, batch_results)
@@ -166,7 +234,7 @@ def run(args, inference=False):
         p1 = test_dataset.eval_multi(("rows", x), protocol2=False, print_verbose=rank == 0, row_offset=lo)
         p2 = test_dataset.eval_multi(("rows", x), protocol2=True, print_verbose=rank == 0, row_offset=lo)
         errs = (p1, p2)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

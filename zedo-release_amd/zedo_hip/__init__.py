@@ -45,8 +45,10 @@ SIGNATURES = {
     "zedo_score_eps": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "zedo_sde_step": (_i, [_vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "zedo_oil_run": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _vp, _sz, _vp]),
-    "zedo_ipo_fit": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _vp]),
-    "zedo_rotate_init": (_i, [_vp, _vp, _vp, _i, _i, _i, _ll, _vp]),
+    "zedo_ipo_fit": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _vp]),
+    "zedo_ipo_fit_resume": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                 _i, _ll, _vp]),
+    "zedo_rotate_init": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _vp]),
     "zedo_min_mpjpe": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp]),
     "zedo_profile_start": (_i, [_i, _i]),
     "zedo_profile_stop": (_i, [_vp, _vp, _vp]),
@@ -69,9 +71,15 @@ def _check(rc):
         raise ZedoError(f"libzedo_hip: {_lib.zedo_error_string(rc).decode()} (code {rc})")
 
 
+_gpu_seen = False
+
+
 def _need_gpu():
-    if not torch.cuda.is_available():
-        raise ZedoError("libzedo_hip needs an MI355X (gfx950): no GPU is visible and there is no CPU path")
+    global _gpu_seen
+    if not _gpu_seen:           # torch.cuda.is_available() costs ~20 us per call; a GPU does not go away
+        if not torch.cuda.is_available():
+            raise ZedoError("libzedo_hip needs an MI355X (gfx950): no GPU is visible and there is no CPU path")
+        _gpu_seen = True
 
 
 def _p(t, dtype=torch.float32):
@@ -230,19 +238,26 @@ def axes_mask(axes):
 
 
 def ipo_fit(x0, uv, K, keylist, axes, ipo_T, min_scale, max_scale, iters, normaliser, B, row_offset=0,
-            return_params=False):
-    """x0 [H,J,3] centred cluster poses, uv [N,J,2], K [N,3,3] -> R [B,3,3], T [B,3] (, q [B,4], scale [B])."""
+            return_params=False, state=None, it_begin=0):
+    """x0 [H,J,3] centred cluster poses, uv [N,J,2], K [N,3,3] -> R [B,3,3], T [B,3] (, q [B,4], scale [B]).
+    state [B,15] (optional, in/out) + it_begin: resume from a captured Adam state (zedo_ipo_fit_resume)."""
     _need_gpu()
-    N, J = uv.shape[0], uv.shape[1]
+    N, J, H = uv.shape[0], uv.shape[1], x0.shape[0]
     dev = uv.device
     R = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
     T = torch.empty((B, 3), dtype=torch.float32, device=dev)
     q = torch.empty((B, 4), dtype=torch.float32, device=dev) if return_params else None
     sc = torch.empty((B,), dtype=torch.float32, device=dev) if return_params else None
     kl = (ctypes.c_int * len(keylist))(*[int(k) for k in keylist])
-    _check(_lib.zedo_ipo_fit(_p(x0), _p(uv), _p(K), ctypes.cast(kl, _vp), len(keylist), axes_mask(axes), float(ipo_T),
-                             float(min_scale), float(max_scale), int(iters), float(normaliser), _p(R), _p(T), _p(q),
-                             _p(sc), B, N, J, int(row_offset), _stream()))
+    if state is not None:
+        _check(_lib.zedo_ipo_fit_resume(_p(x0), _p(uv), _p(K), ctypes.cast(kl, _vp), len(keylist), axes_mask(axes),
+                                        float(ipo_T), float(min_scale), float(max_scale), int(iters), float(normaliser),
+                                        _p(R), _p(T), _p(q), _p(sc), _p(state), int(it_begin), B, H, N, J,
+                                        int(row_offset), _stream()))
+    else:
+        _check(_lib.zedo_ipo_fit(_p(x0), _p(uv), _p(K), ctypes.cast(kl, _vp), len(keylist), axes_mask(axes),
+                                 float(ipo_T), float(min_scale), float(max_scale), int(iters), float(normaliser),
+                                 _p(R), _p(T), _p(q), _p(sc), B, H, N, J, int(row_offset), _stream()))
     return (R, T, q, sc) if return_params else (R, T)
 
 
@@ -250,7 +265,7 @@ def rotate_init(x0, R, N, row_offset=0):
     _need_gpu()
     B, J = R.shape[0], x0.shape[1]
     x = torch.empty((B, J, 3), dtype=torch.float32, device=R.device)
-    _check(_lib.zedo_rotate_init(_p(x0), _p(R), _p(x), B, N, J, int(row_offset), _stream()))
+    _check(_lib.zedo_rotate_init(_p(x0), _p(R), _p(x), B, x0.shape[0], N, J, int(row_offset), _stream()))
     return x
 
 

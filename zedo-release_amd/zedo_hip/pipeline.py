@@ -76,8 +76,14 @@ class Pipeline:
     def run(self, row_offset=0, rows=None, oil_steps=None):
         """IPO + OIL for global rows [row_offset, row_offset+rows) -> (x [rows,17,3], T [rows,3]) on device."""
         c = self.cfg
+        row_offset = int(row_offset)
         B = self.H * self.N - row_offset if rows is None else int(rows)
         S = c.OIL_iterations if oil_steps is None else int(oil_steps)
+        if row_offset < 0 or B < 0 or row_offset + B > self.H * self.N:
+            raise ValueError(f"rows [{row_offset}, {row_offset + B}) are outside the {self.H} x {self.N} problem")
+        if B == 0:          # more ranks than rows: this rank holds an empty shard
+            return (torch.empty((0, self.x0.shape[1], 3), dtype=torch.float32, device=self.device),
+                    torch.empty((0, 3), dtype=torch.float32, device=self.device))
         with torch.cuda.device(self.device):
             R, T = ipo_fit(self.x0, self.uv, self.K, c.IPO_keylist, c.RotAxes, c.IPO_T, c.IPO_minScaleT,
                            c.IPO_maxScaleT, c.IPO_iterations, self.N * len(c.IPO_keylist) * 2, B, row_offset)
@@ -88,25 +94,65 @@ class Pipeline:
     def select(self, x, gt_centred, row_offset=0):
         """-> dict(p1=(best[N], idx[N]), p2=(best[N], idx[N])) for the local rows (fp64 / int32 tensors)."""
         gt = self._dev(gt_centred, torch.float64)
+        if x.shape[0] == 0:
+            return {k: empty_selection(self.N, self.device) for k in ("p1", "p2")}
         with torch.cuda.device(self.device):
             _, b1, i1 = min_mpjpe(x, gt, self.N, False, row_offset)
             _, b2, i2 = min_mpjpe(x, gt, self.N, True, row_offset)
         return dict(p1=(b1, i1), p2=(b2, i2))
 
 
+def empty_selection(N, device):
+    """What zedo_min_mpjpe reports for poses without a local row: (+inf, -1)."""
+    return (torch.full((N,), float("inf"), dtype=torch.float64, device=device),
+            torch.full((N,), -1, dtype=torch.int32, device=device))
+
+
+def force_dist():
+    """ZEDO_FORCE_DIST=1 (alias ZEDO_BENCH_FORCE_DIST): take the multi-rank code path (process group, RCCL
+    collectives) with WORLD_SIZE = 1 too - how the exchange step is exercised on a one-GPU box."""
+    return os.environ.get("ZEDO_FORCE_DIST") == "1" or os.environ.get("ZEDO_BENCH_FORCE_DIST") == "1"
+
+
+def dist_active():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_dist())
+
+
 def reduce_min_over_ranks(best, idx):
     """The one exchange step of the sharded path: MIN over ranks of the per-pose error (RCCL all-reduce),
-    then the lowest hypothesis index among the ranks that hold that minimum."""
+    then the lowest hypothesis index among the ranks that hold that minimum.  NaN follows np.amin / np.argmin
+    (lib/dataset/h36m.py:411-412): a NaN on any rank wins and the lowest NaN hypothesis is reported; it travels
+    as -inf (errors are >= 0) because a collective MIN does not define its NaN behaviour."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or \
-            (dist.get_world_size() == 1 and os.environ.get("ZEDO_BENCH_FORCE_DIST") != "1"):
+    if not dist_active():
         return best, idx
-    g = best.clone()
+    big = 2 ** 31 - 1
+    key = torch.where(torch.isnan(best), torch.full_like(best, float("-inf")), best)
+    g = key.clone()
     dist.all_reduce(g, op=dist.ReduceOp.MIN)
-    cand = torch.where(best == g, idx.to(torch.int64), torch.full_like(idx, 2 ** 31 - 1, dtype=torch.int64))
-    cand = torch.where(idx < 0, torch.full_like(cand, 2 ** 31 - 1), cand)
+    cand = torch.where((key == g) & (idx >= 0), idx.to(torch.int64), torch.full_like(idx, big, dtype=torch.int64))
     dist.all_reduce(cand, op=dist.ReduceOp.MIN)
+    cand = torch.where(cand == big, torch.full_like(cand, -1), cand)        # a pose no rank holds
+    g = torch.where(g == float("-inf"), torch.full_like(g, float("nan")), g)
     return g, cand.to(torch.int32)
+
+
+def gather_row_shards(x_local, total_rows):
+    """All ranks' contiguous row shards (the split of shard_rows) -> the full [total_rows, ...] tensor on every
+    rank: one all-gather of equally sized (last one padded) shards.  run.inference writes every hypothesis of
+    every pose (run/inference.py:233-236), so its result cannot stay sharded."""
+    import torch.distributed as dist
+    if not dist_active():
+        assert x_local.shape[0] == total_rows
+        return x_local
+    world = dist.get_world_size()
+    per = -(-total_rows // world)
+    pad = torch.zeros((per,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
+    pad[:x_local.shape[0]] = x_local
+    out = torch.empty((world * per,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
+    dist.all_gather_into_tensor(out, pad)
+    return out[:total_rows]
 
 
 def shard_rows(total_rows, rank, world):
