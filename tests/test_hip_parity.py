@@ -483,7 +483,7 @@ def test_bad_arguments_are_rejected(zh, W):
     assert b"argument" in lib.zedo_error_string(-1)
 
 
-def test_row_chunking_is_bitwise_neutral(tmp_path):
+def test_row_chunking_and_reprojection_fusion_are_bitwise_neutral(tmp_path):
     """ZEDO_CHUNK_ROWS bounds the workspace for very large batches (BASELINE config 5: 5 M rows); the chunk
     loop must give exactly the rows of the unchunked run.  Separate processes: the cap is read once."""
     import subprocess, sys, os
@@ -506,9 +506,13 @@ zh.oil_run(W, s, x, geom, T, 0, S, 2)
 np.savez(sys.argv[1], x=x.cpu().numpy(), T=T.cpu().numpy(), ws=zh.workspace_bytes(H * N))
 ''' % (root, root)
     outs = []
-    for tag, env in (("full", {}), ("chunk", {"ZEDO_CHUNK_ROWS": "512"})):
+    # "unfused": the reprojection correction as its own launch every iteration (ZEDO_UNFUSED_REPROJ) instead of
+    # riding in the epilogue of the previous iteration's post_dense launch - the same arithmetic, bit for bit
+    for tag, env in (("full", {}), ("chunk", {"ZEDO_CHUNK_ROWS": "512"}), ("unfused", {"ZEDO_UNFUSED_REPROJ": "1"}),
+                     ("unfused_chunk", {"ZEDO_UNFUSED_REPROJ": "1", "ZEDO_CHUNK_ROWS": "320"})):
         out = str(tmp_path / f"{tag}.npz")
         subprocess.run([sys.executable, "-c", code, out], check=True, env={**os.environ, **env})
         outs.append(np.load(out))
-    assert np.array_equal(outs[0]["x"], outs[1]["x"]) and np.array_equal(outs[0]["T"], outs[1]["T"])
+    for o in outs[1:]:
+        assert np.array_equal(outs[0]["x"], o["x"]) and np.array_equal(outs[0]["T"], o["T"])
     assert int(outs[1]["ws"]) == 512 * (64 + 2048) * 4 < int(outs[0]["ws"])

@@ -289,7 +289,7 @@ extern "C" int zedo_schedule_read(const zedo_schedule_t *s, float *h_tbias, floa
     return ZEDO_OK;
 }
 
-static inline size_t ws_rows(int B) { return (size_t)round_up((int)std::min((size_t)B, chunk_rows_cap()), ROW_PAD); }
+static inline size_t ws_rows(int B) { return (size_t)round_up((int)std::min((size_t)B, chunk_rows_cap()), BATCH_PAD); }
 
 extern "C" size_t zedo_workspace_bytes(int B) {
     if (B < 1) return 0;
@@ -312,15 +312,24 @@ extern "C" int zedo_reproj_grad(const float *d_x, const float *d_geom, float *d_
 
 // The six dense layers of one score-network evaluation on Bp padded rows (model.py:264-291), ending either in
 // eps -> xpad (EPI_BIAS, for zedo_score_eps) or in the SDE update of xpad (EPI_SDE).
+struct NextReproj {          // reprojection of the next loop iteration, fused into the SDE epilogue (may be all-null)
+    const float *geom = nullptr;
+    float *T = nullptr;
+    int solve = 0, B = 0, N = 0;
+    long long row0 = 0;
+};
+
 static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad, float *h, float *h1, int Bp, bool sde,
-                             float sa, float sc, float *eps_out, hipStream_t st) {
+                             float sa, float sc, float *eps_out, hipStream_t st, const NextReproj &nr = NextReproj()) {
     LayerArgs a{};
     a.Mp = Bp;
     // pre_dense + pre_gnorm + SiLU
     a.X = xpad; a.ldx = XLD; a.W = w->W_pre; a.ldw = XLD; a.K = XLD; a.N = HID;
+    a.kzero8 = w->J3 <= XLD - 8;   // 51 real inputs: k = 56..63 are zero in xpad and in the padded weight
     a.bias = tb; a.gamma = w->gamma[0]; a.beta = w->beta[0]; a.out = h; a.ldo = HID;
     hipError_t e;
     { ProfScope ps(ZEDO_PROF_PRE, st); e = launch_layer(a, EPI_GN_SILU, st); }
+    a.kzero8 = 0;
     for (int blk = 0; blk < 2 && e == hipSuccess; ++blk) {
         const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
         a.X = h; a.ldx = HID; a.W = w->W_hid[l1 - 1]; a.ldw = HID; a.K = HID; a.N = HID;
@@ -335,7 +344,11 @@ static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad
     a.X = h; a.ldx = HID; a.W = w->W_post; a.ldw = HID; a.K = HID; a.N = XLD; a.bias = w->b_post;
     a.gamma = a.beta = nullptr; a.ldo = XLD;
     ProfScope ps(ZEDO_PROF_POST, st);
-    if (sde) { a.out = xpad; a.sde_a = sa; a.sde_c = sc; return launch_layer(a, EPI_SDE, st); }
+    if (sde) {
+        a.out = xpad; a.sde_a = sa; a.sde_c = sc;
+        a.rp_geom = nr.geom; a.rp_T = nr.T; a.rp_solve = nr.solve; a.rp_B = nr.B; a.rp_N = nr.N; a.rp_row0 = nr.row0;
+        return launch_layer(a, EPI_SDE, st);
+    }
     a.out = eps_out;
     return launch_layer(a, EPI_BIAS, st);
 }
@@ -354,7 +367,7 @@ static int step_common(const zedo_weights_t *w, const zedo_schedule_t *s, int st
     const size_t cap = chunk_rows_cap();
     const float *tb = s->d_tbias + (size_t)step * NLAYER * HID;
     for (size_t r0 = 0; r0 < (size_t)B; r0 += cap) {
-        const int Bc = (int)std::min(cap, (size_t)B - r0), Bp = round_up(Bc, ROW_PAD);
+        const int Bc = (int)std::min(cap, (size_t)B - r0), Bp = round_up(Bc, BATCH_PAD);
         Ws k = carve(ws, B);
         HIPCHK(launch_pack_rows(d_x_in + r0 * w->J3, k.xpad, Bc, Bp, w->J3, st));
         if (sde) {
@@ -388,19 +401,27 @@ extern "C" int zedo_oil_run(const zedo_weights_t *w, const zedo_schedule_t *s, f
     hipStream_t st = (hipStream_t)stream;
     const size_t cap = chunk_rows_cap();
     for (size_t r0 = 0; r0 < (size_t)B; r0 += cap) {
-        const int Bc = (int)std::min(cap, (size_t)B - r0), Bp = round_up(Bc, ROW_PAD);
+        const int Bc = (int)std::min(cap, (size_t)B - r0), Bp = round_up(Bc, BATCH_PAD);
         Ws k = carve(d_workspace, B);
         HIPCHK(launch_pack_rows(d_x + r0 * w->J3, k.xpad, Bc, Bp, w->J3, st));
+        // gradient_field_gen + "denoise_x += joint_gradient" (run/opt_main.py:203-208) of the first iteration; the
+        // correction of every later iteration i+1 rides in the epilogue of iteration i's post_dense launch
+        // (ZEDO_UNFUSED_REPROJ=1: one launch per iteration, the A/B and parity reference)
+        static const bool unfused = getenv("ZEDO_UNFUSED_REPROJ") != nullptr;
         for (int i = step_begin; i < step_end; ++i) {
-            // gradient_field_gen + "denoise_x += joint_gradient" (run/opt_main.py:203-208)
-            {
+            if (i == step_begin || unfused) {
                 ProfScope ps(ZEDO_PROF_REPROJ, st);
                 HIPCHK(launch_reproj_step_padded(k.xpad, d_geom, d_T + r0 * 3, i >= switch_step, Bc, N,
                                                  row_offset + (long long)r0, st));
             }
-            // sampling_fn(...) (run/opt_main.py:210-218) -> x = a_i x + c_i eps(x, t_i)
+            NextReproj nr;
+            if (i + 1 < step_end && !unfused) {
+                nr.geom = d_geom; nr.T = d_T + r0 * 3; nr.solve = (i + 1) >= switch_step; nr.B = Bc; nr.N = N;
+                nr.row0 = row_offset + (long long)r0;
+            }
+            // sampling_fn(...) (run/opt_main.py:210-218) -> x = a_i x + c_i eps(x, t_i)  [+ the next correction]
             HIPCHK(mlp_layers(w, s->d_tbias + (size_t)i * NLAYER * HID, k.xpad, k.h, k.h1, Bp, true, s->a[i], s->c[i],
-                              nullptr, st));
+                              nullptr, st, nr));
         }
         HIPCHK(launch_unpack_rows(k.xpad, d_x + r0 * w->J3, Bc, w->J3, st));
     }

@@ -159,7 +159,10 @@ __device__ long long *g_timeline = nullptr;   // ubench only: 8 x int64 per work
 // that hides it (the compiler otherwise sinks the ds_reads to their first use and exposes the LDS latency);
 // bit 1 = issue the DMA of a tile one instruction at a time between the MFMAs of the two groups that follow the
 // barrier instead of as one burst right behind it.
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0>
+// KSKIP (K == NBUF * BK only, i.e. the ring holds all of K): the last KSKIP fragment groups (8 k each) of the last
+// tile are known to be zero in both operands and their MFMAs are not issued - pre_dense: K = 51 padded to 64, the
+// group k = 56..63 is padding on both sides; skipping exact zeros leaves every sum bit-identical.
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int KSKIP = 0>
 __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, const int nwg) {
     constexpr int NW = WM * WN;
     constexpr int CPR = BK / 4;                         // 16-byte chunks per tile row (8 or 4)
@@ -337,6 +340,7 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
             if constexpr (SCHED & 1) __builtin_amdgcn_sched_barrier(0);
             mma(fa0, fb0);
         }
+        const bool skip_last = KSKIP == 1 && KG == 4 && buf == NBUF - 1;   // group 3 of the last tile is all zeros (folds: buf is unrolled)
         if constexpr (SCHED & 4) __builtin_amdgcn_sched_barrier(0);   // keep the barrier behind the whole MFMA group
         // hipcc (ROCm 7.2) emits only lgkmcnt(0) before this barrier: it does not count the outstanding LDS-DMA,
         // so wait explicitly until tile kt+1 has landed (the NBUF-2 younger tiles may stay in flight).
@@ -344,7 +348,9 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
         __syncthreads();
         // Branch-free on purpose (one basic block, so these issue under the MFMAs below): past the last
         // tile the DMA refills a buffer nobody reads again and the fragment read fetches unused values.
-        if constexpr (SCHED & 2) {
+        if (skip_last) {
+            // nothing left to issue: the tile after the last one does not exist
+        } else if constexpr (SCHED & 2) {
             fread(fa0, fb0, nxt, 0);
             __builtin_amdgcn_sched_barrier(0);
             mma_dma(fa1, fb1, min(kt + NBUF, KT - 1), buf, 0, H1);
@@ -435,6 +441,38 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
                 }
             }
             __syncthreads();
+            if constexpr (EPI == EPI_SDE && BN == XLD) {
+                // reprojection correction of the next iteration on the updated rows, one lane per row, straight from the
+                // stage (chunk c of stage row sr sits at position c ^ (sr & 7)); same source as reproj_step_kernel
+                if (a.rp_geom != nullptr) {
+                    constexpr int NV = (17 * 3 + 3) / 4;
+                    if (tid < SR) {
+                        const int sr = tid;
+                        const int b = m0 + (sr >> 5) * TM + j * 32 + (sr & 31);
+                        if (b < a.rp_B) {
+                            float xr[NV * 4], gr[17 * 3], Tr[3];
+                            float *srow = S + sr * BN;
+#pragma unroll
+                            for (int v = 0; v < NV; ++v) {
+                                const f32x4 t = *reinterpret_cast<const f32x4 *>(srow + ((v ^ (sr & 7)) << 2));
+                                xr[4 * v] = t[0]; xr[4 * v + 1] = t[1]; xr[4 * v + 2] = t[2]; xr[4 * v + 3] = t[3];
+                            }
+                            Tr[0] = a.rp_T[(size_t)b * 3]; Tr[1] = a.rp_T[(size_t)b * 3 + 1]; Tr[2] = a.rp_T[(size_t)b * 3 + 2];
+                            const int n = (int)((a.rp_row0 + b) % a.rp_N);
+                            reproj_row<17>(xr, a.rp_geom + (size_t)n * 17 * GEOM_F, Tr, a.rp_solve != 0, gr);
+                            if (a.rp_solve) { a.rp_T[(size_t)b * 3] = Tr[0]; a.rp_T[(size_t)b * 3 + 1] = Tr[1]; a.rp_T[(size_t)b * 3 + 2] = Tr[2]; }
+#pragma unroll
+                            for (int c = 0; c < 17 * 3; ++c) xr[c] += gr[c];
+#pragma unroll
+                            for (int v = 0; v < NV; ++v) {
+                                const f32x4 t = {xr[4 * v], xr[4 * v + 1], xr[4 * v + 2], xr[4 * v + 3]};
+                                *reinterpret_cast<f32x4 *>(srow + ((v ^ (sr & 7)) << 2)) = t;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
 #pragma unroll
             for (int pass = 0; pass < SR * CPRW / NT; ++pass) {
                 const int qi = pass * NT + tid;
@@ -460,9 +498,9 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1>
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1, int KSKIP = 0>
 __global__ __launch_bounds__(WM *WN * 64, WPE) void layer_kernel(LayerArgs a) {
-    layer_body<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED>(a, blockIdx.x, gridDim.x);
+    layer_body<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP>(a, blockIdx.x, gridDim.x);
 }
 
 // One launch, two tile shapes: workgroups [0, nbig) run 128x128 tiles on the rows that fill whole rounds of the
@@ -536,11 +574,12 @@ static hipError_t launch_pair(const LayerArgs &big, const LayerArgs &small, hipS
     return hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1>
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1, int KSKIP = 0>
 static hipError_t launch_cfg(const LayerArgs &a, hipStream_t st) {
     constexpr size_t lds = ((size_t)NBUF * (BM + BN) * BK + 3 * BN) * sizeof(float);
     if (a.Mp <= 0 || a.Mp % BM || a.N % BN || a.K % (BK * NBUF)) return hipErrorInvalidValue;
-    auto kern = layer_kernel<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, WPE>;
+    if (KSKIP && a.K != BK * NBUF) return hipErrorInvalidValue;
+    auto kern = layer_kernel<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, WPE, KSKIP>;
     static std::atomic<bool> attr_done[MAX_DEVICES];      // per instantiation and per device
     if (hipError_t e = allow_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const int nwg = (a.Mp / BM) * (a.N / BN);
@@ -599,10 +638,14 @@ static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
     // K <= 64 (pre_dense): almost no MFMA work per output, the layer is bound by writing the activation:
     // many small co-resident workgroups overlap their stores, one big tile per CU cannot.
     // (measured at 50 750 rows: 64x128 82 us; 32x128 92 us; 128x128 91 us; 64x256 108 us)
-    if (a.K <= 64) return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);
+    if (a.K <= 64) {
+        // a.kpad_zero_groups: the caller vouches that k >= K - 8 is zero in X and W (pre_dense: 51 real inputs)
+        if (a.K == 64 && a.kzero8) return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN, 1, 1>(a, st);
+        return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);
+    }
     const int per_round = num_cus() * 2 * 128 / (a.N / 128);      // rows covered by one full round of 128x128 tiles, 2 per CU
     const int rows_big = (a.Mp / per_round) * per_round;
-    const int rows_small = a.Mp - rows_big;                       // multiple of 256 (ROW_PAD)
+    const int rows_small = a.Mp - rows_big;                       // multiple of 64 (BATCH_PAD)
     static const bool split_launch = getenv("ZEDO_SPLIT_REMAINDER") != nullptr;   // A/B knob: remainder as its own launch
     if (rows_small > 0 && rows_big > 0 && !split_launch) {
         // eight-wave workgroups bring 64-row remainder tiles along; a short remainder finishes sooner as 32-row tiles

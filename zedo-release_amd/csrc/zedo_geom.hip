@@ -6,10 +6,7 @@
 
 namespace zedo {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// geom[n][j] = 8 floats: { r_x, r_y, W, 0,  rhat_x, rhat_y, rhat_z, 0 }
-constexpr int GEOM_F = 8;
+// f32x4, GEOM_F and reproj_row<J>: zedo_internal.h
 
 // ------------------------------------------------------------------------------------------
 // pose rows [B][D] <-> padded rows [Bp][XLD] (pad columns and pad rows are zero)
@@ -87,50 +84,8 @@ hipError_t launch_reproj_prepare(const float *uv, const float *K, const float *c
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------
-// gradient_field_gen for one pose row held in registers (simple_zeroshot_opt.py:73-109)
-// ------------------------------------------------------------------------------------------
-// Weighted least squares for T, centred closed form of the 3x3 normal equations of :73-92:
-//   minimise sum_j W_j [(-T_x + r_xj T_z - b_xj)^2 + (-T_y + r_yj T_z - b_yj)^2],  b = x_xy - x_z r_xy
-//   T_z = sum W[(r_x-rbar_x)(b_x-bbar_x) + (r_y-rbar_y)(b_y-bbar_y)] / sum W[(r_x-rbar_x)^2 + (r_y-rbar_y)^2]
-//   T_xy = rbar_xy T_z - bbar_xy ;  T <- -T if T_z < 0 (:93)
-template <int J>
-__device__ __forceinline__ void reproj_row(const float *x, const float *__restrict__ gp, float *T, bool solve,
-                                           float *g) {
-    if (solve) {
-        float sw = 0.f, srx = 0.f, sry = 0.f, sbx = 0.f, sby = 0.f;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(gp + j * GEOM_F);
-            const float bx = x[3 * j] - x[3 * j + 2] * a[0], by = x[3 * j + 1] - x[3 * j + 2] * a[1];
-            sw += a[2]; srx += a[2] * a[0]; sry += a[2] * a[1]; sbx += a[2] * bx; sby += a[2] * by;
-        }
-        const float iw = 1.0f / sw;
-        const float mrx = srx * iw, mry = sry * iw, mbx = sbx * iw, mby = sby * iw;
-        float num = 0.f, den = 0.f;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(gp + j * GEOM_F);
-            const float bx = x[3 * j] - x[3 * j + 2] * a[0], by = x[3 * j + 1] - x[3 * j + 2] * a[1];
-            const float dx = a[0] - mrx, dy = a[1] - mry;
-            num += a[2] * (dx * (bx - mbx) + dy * (by - mby));
-            den += a[2] * (dx * dx + dy * dy);
-        }
-        float tz = num / den;
-        float tx = mrx * tz - mbx, ty = mry * tz - mby;
-        if (tz < 0.f) { tx = -tx; ty = -ty; tz = -tz; }
-        T[0] = tx; T[1] = ty; T[2] = tz;
-    }
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const f32x4 rh = *reinterpret_cast<const f32x4 *>(gp + j * GEOM_F + 4);
-        const float px = x[3 * j] + T[0], py = x[3 * j + 1] + T[1], pz = x[3 * j + 2] + T[2];
-        const float d = px * rh[0] + py * rh[1] + pz * rh[2];
-        g[3 * j] = d * rh[0] - px;
-        g[3 * j + 1] = d * rh[1] - py;
-        g[3 * j + 2] = d * rh[2] - pz;
-    }
-}
+// reproj_row<J> (gradient_field_gen for one pose row held in registers) lives in zedo_internal.h: the fused
+// post_dense + reprojection + pre_dense kernel of zedo_gemm.hip runs the same source.
 
 // Standalone surface op: x [B][J*3] -> g [B][J*3] (+T).  128 rows per workgroup, tile staged through
 // LDS with unit-stride global accesses; odd row stride (51) keeps the per-lane row reads conflict free.
@@ -173,17 +128,17 @@ hipError_t launch_reproj_grad(const float *x, const float *geom, float *T, int s
     return hipGetLastError();
 }
 
-// Fused-loop variant on the padded state: xpad[row][64] += g, in place.  128 rows per workgroup:
-// the 32 KB tile moves as 16-byte, fully coalesced accesses through LDS (row stride 68 floats so
+// Fused-loop variant on the padded state: xpad[row][64] += g, in place.  64 rows (one wavefront) per workgroup:
+// the 16 KB tile moves as 16-byte, fully coalesced accesses through LDS (row stride 68 floats so
 // that each lane's ds_read_b128 / ds_write_b128 of its own row is bank-conflict free).
 template <int J>
-__global__ __launch_bounds__(128) void reproj_step_kernel(float *__restrict__ xpad, const float *__restrict__ geom,
-                                                          float *__restrict__ T, int solve, int B, int N,
-                                                          long long row_offset) {
-    constexpr int D = J * 3, R = 128, LD = XLD + 4, NV = (D + 3) / 4;
+__global__ __launch_bounds__(64) void reproj_step_kernel(float *__restrict__ xpad, const float *__restrict__ geom,
+                                                         float *__restrict__ T, int solve, int B, int N,
+                                                         long long row_offset) {
+    constexpr int D = J * 3, R = BATCH_PAD, LD = XLD + 4, NV = (D + 3) / 4;
     __shared__ __attribute__((aligned(16))) float sx[R * LD];
     const int row0 = blockIdx.x * R, tid = threadIdx.x;
-    float *base = xpad + (size_t)row0 * XLD;  // Bp is a multiple of 256: the whole tile exists
+    float *base = xpad + (size_t)row0 * XLD;  // Bp is a multiple of BATCH_PAD: the whole tile exists
 #pragma unroll
     for (int it = 0; it < XLD / 4; ++it) {
         const int idx = it * R + tid, r = idx >> 4, c4 = idx & 15;
@@ -220,8 +175,8 @@ __global__ __launch_bounds__(128) void reproj_step_kernel(float *__restrict__ xp
 
 hipError_t launch_reproj_step_padded(float *xpad, const float *geom, float *T, int solve_T, int B, int N,
                                      long long row0, hipStream_t st) {
-    hipLaunchKernelGGL(reproj_step_kernel<17>, dim3((B + 127) / 128), dim3(128), 0, st, xpad, geom, T, solve_T, B, N,
-                       row0);
+    hipLaunchKernelGGL(reproj_step_kernel<17>, dim3((B + BATCH_PAD - 1) / BATCH_PAD), dim3(BATCH_PAD), 0, st, xpad, geom, T,
+                       solve_T, B, N, row0);
     return hipGetLastError();
 }
 

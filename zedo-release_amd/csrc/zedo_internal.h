@@ -9,7 +9,8 @@ namespace zedo {
 constexpr int HID = 1024;    // hidden width of ScoreModelFC_Adv (reference run/opt_main.py:35)
 constexpr int EMB = 512;     // time-embedding width (run/opt_main.py:36)
 constexpr int XLD = 64;      // padded row length of the pose state: J*3 = 51 floats + 13 zeros
-constexpr int ROW_PAD = 256; // rows of every activation buffer are padded to a multiple of this
+constexpr int ROW_PAD = 256; // rows of the schedule tables are padded to a multiple of this (one round of 32-row tiles)
+constexpr int BATCH_PAD = 64; // pose rows of a call are padded to a multiple of this: the smallest row tile every layer accepts
 constexpr int NLAYER = 5;    // hidden layers with a time bias: pre + 2 blocks x 2
 
 enum Epilogue : int {
@@ -33,9 +34,67 @@ struct LayerArgs {
     int N;               // multiple of the tile's BN
     int Mp;              // multiple of the tile's BM
     float sde_a, sde_c;  // EPI_SDE
+    int kzero8;          // K == 64 only: columns k = 56..63 of X and W are zero padding (their MFMAs are skipped)
+    // EPI_SDE only, optional (rp_geom != nullptr): the reprojection correction of the NEXT loop iteration
+    // (gradient_field_gen + "denoise_x += joint_gradient", run/opt_main.py:203-208) applied to the freshly updated rows
+    // while they are still in LDS, instead of a separate launch that reads and rewrites them.
+    const float *rp_geom;   // [N][17][8]
+    float *rp_T;            // [rows][3], row 0 = first row of this launch
+    int rp_solve, rp_B, rp_N;   // least-squares T?, valid rows of this launch, poses
+    long long rp_row0;      // global row index of row 0 of this launch
 };
 
 hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// geom[n][j] = 8 floats: { r_x, r_y, W, 0,  rhat_x, rhat_y, rhat_z, 0 }   (zedo_reproj_prepare)
+constexpr int GEOM_F = 8;
+
+// gradient_field_gen for one pose row held in registers (simple_zeroshot_opt.py:73-109)
+// Weighted least squares for T, centred closed form of the 3x3 normal equations of :73-92:
+//   minimise sum_j W_j [(-T_x + r_xj T_z - b_xj)^2 + (-T_y + r_yj T_z - b_yj)^2],  b = x_xy - x_z r_xy
+//   T_z = sum W[(r_x-rbar_x)(b_x-bbar_x) + (r_y-rbar_y)(b_y-bbar_y)] / sum W[(r_x-rbar_x)^2 + (r_y-rbar_y)^2]
+//   T_xy = rbar_xy T_z - bbar_xy ;  T <- -T if T_z < 0 (:93)
+template <int J>
+__device__ __forceinline__ void reproj_row(const float *x, const float *__restrict__ gp, float *T, bool solve,
+                                           float *g) {
+    if (solve) {
+        float sw = 0.f, srx = 0.f, sry = 0.f, sbx = 0.f, sby = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(gp + j * GEOM_F);
+            const float bx = x[3 * j] - x[3 * j + 2] * a[0], by = x[3 * j + 1] - x[3 * j + 2] * a[1];
+            sw += a[2]; srx += a[2] * a[0]; sry += a[2] * a[1]; sbx += a[2] * bx; sby += a[2] * by;
+        }
+        const float iw = 1.0f / sw;
+        const float mrx = srx * iw, mry = sry * iw, mbx = sbx * iw, mby = sby * iw;
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(gp + j * GEOM_F);
+            const float bx = x[3 * j] - x[3 * j + 2] * a[0], by = x[3 * j + 1] - x[3 * j + 2] * a[1];
+            const float dx = a[0] - mrx, dy = a[1] - mry;
+            num += a[2] * (dx * (bx - mbx) + dy * (by - mby));
+            den += a[2] * (dx * dx + dy * dy);
+        }
+        float tz = num / den;
+        float tx = mrx * tz - mbx, ty = mry * tz - mby;
+        if (tz < 0.f) { tx = -tx; ty = -ty; tz = -tz; }
+        T[0] = tx; T[1] = ty; T[2] = tz;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const f32x4 rh = *reinterpret_cast<const f32x4 *>(gp + j * GEOM_F + 4);
+        const float px = x[3 * j] + T[0], py = x[3 * j + 1] + T[1], pz = x[3 * j + 2] + T[2];
+        const float d = px * rh[0] + py * rh[1] + pz * rh[2];
+        g[3 * j] = d * rh[0] - px;
+        g[3 * j + 1] = d * rh[1] - py;
+        g[3 * j + 2] = d * rh[2] - pz;
+    }
+}
+
+
 
 // geometry kernels (zedo_geom.hip)
 hipError_t launch_pack_rows(const float *x, float *xpad, int B, int Bp, int D, hipStream_t st);
