@@ -51,7 +51,9 @@ def main():
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs on the chip
             e["mfma_util"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] / 8 * 1024)
     hidden = [e for k, e in merged.items() if k.startswith("layer_pair_kernel") and "hbm_bytes_per_launch" in e]
-    doc = {"note": __doc__.split("usage:")[1].split("\n", 2)[2].strip(), "rows": rows, "kernels": merged}
+    import os
+    doc = {"note": __doc__.split("usage:")[1].split("\n", 2)[2].strip(), "rows": rows,
+           "collected": os.environ.get("ZEDO_PMC_TAG", "unlabelled counter pass"), "kernels": merged}
     if hidden:
         alg = rows * 1024 * 4 * 2.5 + 1024 * 1024 * 4      # read X, write Y, residual on every other layer, + W
         b = sum(e["hbm_bytes_per_launch"] for e in hidden) / len(hidden)
