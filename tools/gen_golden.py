@@ -720,13 +720,15 @@ def gen_driver_full():
          batch_results=batch_results.astype(np.float32))
 
 
-def _driver_full_size(tag, N, H, S, seed_pose, seed_cl, keylist, ipo_T, minT, conf_mode, dataset, cache_dir):
+def _driver_full_size(tag, N, H, S, seed_pose, seed_cl, keylist, ipo_T, minT, conf_mode, dataset, cache_dir,
+                      dtype=torch.float32):
     """opt_main.py:166-228 at a BASELINE configuration's stated size.  One hypothesis at a time like the reference;
     each finished hypothesis is parked under cache_dir so that an interrupted capture resumes.  Only small arrays
     are committed: the per-(pose, hypothesis) errors, per-pose best / argmin, dataset means, the IPO outcome as
     (rotation angle about z, depth scale) and the seeds of the inputs."""
     w = syn.make_weights(seed=0)
-    m = ref_model(w)
+    m = ref_model(w, dtype)
+    f64 = dtype == torch.float64          # the arbiter run: every tensor, RotOpt and the network in double
     d = syn.make_poses(N, seed=seed_pose, conf_mode=conf_mode, dtype3d=np.float64 if dataset == "h36m" else np.float32)
     cl = syn.make_clusters(H, seed=seed_cl)
     gt_2d, K = d["db_2d"], d["camera_param"]
@@ -740,10 +742,10 @@ def _driver_full_size(tag, N, H, S, seed_pose, seed_cl, keylist, ipo_T, minT, co
             res, R, Tf, T0, ls = z["res"], z["R"], z["T"], z["T0"], z["loss"]
         else:
             t0 = time.time()
-            noisy = torch.ones((N, 17, 3)) * torch.tensor(cl - cl[:, 0:1, :])[sid:sid + 1]
-            r = run_ref_ipo(noisy.numpy(), gt_2d[:, :, :2], K, "z", keylist, ipo_T, minT, 2.0, 500, trace_upto=1)
+            noisy = (torch.ones((N, 17, 3)) * torch.tensor(cl - cl[:, 0:1, :])[sid:sid + 1]).to(dtype)
+            r = run_ref_ipo(noisy.numpy(), gt_2d[:, :, :2], K, "z", keylist, ipo_T, minT, 2.0, 500, trace_upto=1, dtype=dtype)
             x = torch.tensor(r["R"]).bmm(noisy.permute(0, 2, 1)).permute(0, 2, 1).contiguous().numpy()
-            res, _, _ = run_ref_oil(m, x, gt_2d[:, :, :2], gt_2d[:, :, 2].copy(), K, r["T"], S, [])
+            res, _, _ = run_ref_oil(m, x, gt_2d[:, :, :2], gt_2d[:, :, 2].copy(), K, r["T"], S, [], dtype)
             R, Tf, T0, ls = r["R"], r["T"], r["T0"], r["loss"]
             np.savez(f, res=res, R=R, T=Tf, T0=T0, loss=ls)
             print(f"  {tag}: hypothesis {sid + 1}/{H} in {time.time() - t0:.0f} s", flush=True)
@@ -770,6 +772,11 @@ def _driver_full_size(tag, N, H, S, seed_pose, seed_cl, keylist, ipo_T, minT, co
             e1[n, h] = np.mean(np.sqrt(np.square(batch_results[n, h] - gtc[n]).sum(axis=1)))
             Z = procrustes(gtc[n].copy(), batch_results[n, h].copy())[1]
             e2[n, h] = np.mean(np.sqrt(np.square(Z - gtc[n]).sum(axis=1)))
+    if f64:       # arbiter: only the metric side is kept
+        save(tag, N=np.int64(N), H=np.int64(H), S=np.int64(S), mpjpe=np.float64(p1), pa_mpjpe=np.float64(p2),
+             best_p1=e1.min(1), best_p2=e2.min(1), argmin_p1=e1.argmin(1).astype(np.int32),
+             argmin_p2=e2.argmin(1).astype(np.int32), inputs_sha=np.array(_sha(gt_2d, K, cl)))
+        return
     save(tag, N=np.int64(N), H=np.int64(H), S=np.int64(S), seed_pose=np.int64(seed_pose), seed_cl=np.int64(seed_cl),
          conf_mode=np.array(conf_mode), dataset=np.array(dataset), keylist=np.array(keylist), ipo_T=np.float64(ipo_T),
          minT=np.float64(minT), mpjpe=np.float64(p1), pa_mpjpe=np.float64(p2),
@@ -797,6 +804,19 @@ def gen_driver_h36m_full():
     _driver_full_size("driver_h36m_full", 886, 1, 1000, 101, 17, [0, 1, 4], 3.0, 0.5, "uniform", "h36m", CACHE)
 
 
+def gen_driver_h36m_full_f64():
+    """The same run with the reference in float64 (arbiter for the dataset means: how far is the reference's own fp32
+    run from exact arithmetic on this chaotic loop?)."""
+    _driver_full_size("driver_h36m_full_f64", 886, 1, 1000, 101, 17, [0, 1, 4], 3.0, 0.5, "uniform", "h36m", CACHE,
+                      dtype=torch.float64)
+
+
+def gen_driver_pw3d_full_f64():
+    """float64 arbiter of configs[2] (about twice the CPU time of the fp32 capture); --only driver_pw3d_full_f64."""
+    _driver_full_size("driver_pw3d_full_f64", 1015, 50, 1000, 103, 19, list(range(17)), 8.0, 0.2, "uniform", "3dpw", CACHE,
+                      dtype=torch.float64)
+
+
 def gen_driver_pw3d_full():
     """BASELINE configs[2] at its stated size: N = 1015, H = 50, S = 1000, 17-joint key list, IPO_T 8
     (configs/optim/concat_pose_optimization_pw3d.py:72-81), PW3D.eval_multi.  ~45 CPU-minutes: run once
@@ -808,8 +828,9 @@ def gen_driver_pw3d_full():
 GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo, oil=gen_oil,
             eval=gen_eval, driver=gen_driver, datasets=gen_datasets,
             driver_files=gen_driver_files, samplers=gen_samplers, pc_generic=gen_pc_generic, hp3d_ski=gen_3dhp_ski, driver_full=gen_driver_full,
-            driver_h36m_full=gen_driver_h36m_full, driver_pw3d_full=gen_driver_pw3d_full)
-SLOW = {"driver_pw3d_full"}     # only with --only
+            driver_h36m_full=gen_driver_h36m_full, driver_pw3d_full=gen_driver_pw3d_full,
+            driver_h36m_full_f64=gen_driver_h36m_full_f64, driver_pw3d_full_f64=gen_driver_pw3d_full_f64)
+SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64"}     # only with --only
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
