@@ -67,6 +67,24 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // VALU add per instruction inside the K loop, and VALU issue time is matrix-pipe time here.  M0 (the LDS
 // destination) is compiler-reserved: it is saved and restored inside the statement.  hipcc does not count this load
 // in its vmcnt bookkeeping - every consumer below sits behind an explicit s_waitcnt vmcnt + barrier.
+#ifdef ZEDO_EXP_XSC1   // experiment: activation (X) tiles fetched past the per-XCD L2's non-coherent lines
+#if ZEDO_EXP_XSC1 == 1
+#define ZEDO_XMOD "sc1"
+#elif ZEDO_EXP_XSC1 == 2
+#define ZEDO_XMOD "sc0 sc1"
+#else
+#define ZEDO_XMOD "nt"
+#endif
+__device__ __forceinline__ void dma16x(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 " ZEDO_XMOD "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(sbase), "v"(voff), "s"(lds_byte_addr)
+                 : "memory");
+}
+#else
+#define dma16x dma16
+#endif
 __device__ __forceinline__ void dma16(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
@@ -211,7 +229,7 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
             dma16(Wbase + (size_t)kt * (BK * 4) + (size_t)p * (RPD * 4) * a.ldw, wlane,
                   lds0 + (unsigned)(((buf * BN + (wid * IA + p) * RPD) * BK) * 4));
         else
-            dma16(Xbase + (size_t)kt * (BK * 4) + (size_t)(p - IA) * (RPD * 4) * a.ldx, xlane,
+            dma16x(Xbase + (size_t)kt * (BK * 4) + (size_t)(p - IA) * (RPD * 4) * a.ldx, xlane,
                   lds0 + (unsigned)(((NBUF * BN + buf * BM + (wid * IB + (p - IA)) * RPD) * BK) * 4));
     };
     auto dma = [&](int kt, int buf) {
