@@ -70,3 +70,45 @@ def test_large_shard_slices_are_bitwise_the_full_run(zh, weights0, N, H):
         gi = torch.where(b1 <= b2, i1, i2)
         assert torch.equal(gb, best) and torch.equal(gi, idx)
         assert torch.equal(best, err.reshape(H, N).min(0).values)
+
+
+def test_eight_virtual_ranks_reproduce_the_unsharded_run(zh, weights0):
+    """BASELINE configs[3] / [4] shard the hypothesis-major rows over 8 GPUs (shard_rows, the rule of
+    lib/dataset/EvaSampler.py:78-107) and combine the per-pose minima with MIN all-reduces.  One GPU plays the 8
+    ranks in turn: every rank's Pipeline.run(row_offset, rows) must give exactly its rows of the unsharded run,
+    and the per-rank selections combined the way reduce_min_over_ranks combines them (minimum, then lowest
+    hypothesis index among the holders) must equal the unsharded selection - IPO normaliser, row_offset
+    arithmetic, uneven last shard and shard boundaries inside a hypothesis included (H*N = 50*2003 rows)."""
+    from lib.dataset import synthetic as syn
+    from zedo_hip.pipeline import Pipeline, ZeDOConfig, shard_rows
+    N, H, S, world = 2003, 50, 12, 8
+    d = syn.make_poses(N, seed=808, conf_mode="uniform")
+    cl = syn.make_clusters(H, seed=808)
+    pipe = Pipeline(weights0, ZeDOConfig.pw3d(OIL_iterations=S), "cuda").load(cl, d["db_2d"], d["camera_param"])
+    x_full, T_full = pipe.run()
+    gt = (d["db_3d"] - d["db_3d"][:, 0:1]).astype(np.float64)
+    sel_full = pipe.select(x_full, gt)
+    big = 2 ** 31 - 1
+    acc = {k: (torch.full((N,), float("inf"), dtype=torch.float64, device="cuda"),
+               torch.full((N,), big, dtype=torch.int64, device="cuda")) for k in ("p1", "p2")}
+    parts = []
+    covered = 0
+    for rank in range(world):
+        lo, rows = shard_rows(H * N, rank, world)
+        assert lo == covered
+        covered += rows
+        x, T = pipe.run(row_offset=lo, rows=rows)
+        assert torch.equal(x, x_full[lo:lo + rows]) and torch.equal(T, T_full[lo:lo + rows]), rank
+        parts.append((lo, rows))
+        sel = pipe.select(x, gt, row_offset=lo)
+        for k in ("p1", "p2"):
+            b, i = sel[k]
+            i = torch.where(i < 0, torch.full_like(i, big), i).long()
+            gb, gi = acc[k]
+            nb = torch.minimum(gb, b)
+            ni = torch.minimum(torch.where(gb == nb, gi, torch.full_like(gi, big)),
+                               torch.where(b == nb, i, torch.full_like(i, big)))
+            acc[k] = (nb, ni)
+    assert covered == H * N and len({r for _, r in parts}) <= 2          # contiguous, unpadded, at most one short shard
+    for k in ("p1", "p2"):
+        assert torch.equal(acc[k][0], sel_full[k][0]) and torch.equal(acc[k][1], sel_full[k][1].long()), k
