@@ -208,7 +208,8 @@ def main():
             "metric": "poses/sec (1000-step sampler, H=50)", "value": round(poses_per_s, 3), "unit": "poses/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2] shape (3DPW): N={a.poses} poses/GPU x H={H} hypotheses, "
+            "config": {"workload": ("BASELINE configs[2] shape (3DPW)" if (a.poses, H, S) == (N_POSES, N_HYPO, S_OIL)
+                                    else "3DPW settings, non-default size") + f": N={a.poses} poses/GPU x H={H} hypotheses, "
                                    f"IPO 500 it (17 joints) + {S} OIL steps + P1/P2 min-over-hypotheses selection; "
                                    "random-init ScoreModelFC_Adv weights, synthetic detections",
                        "rows_per_gpu": rows, "poses_total": N_total, "sharding": f"rows over {world} rank(s)"},
