@@ -420,7 +420,8 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
                     const int sr = idx * RPI + lane / CPRW, pos = lane % CPRW;
                     const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
                     __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(obase + (size_t)grow * a.ldo + (pos ^ (sr & 7)) * 4),
+                        (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(obase) +
+                                                                         ((unsigned)grow * (unsigned)a.ldo + (unsigned)((pos ^ (sr & 7)) * 4)) * 4u),
                         (__attribute__((address_space(3))) void *)(S + idx * RPI * BN), 16, 0, 0);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -497,7 +498,10 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
                 const int sr = qi / CPRW, c = qi % CPRW;
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(S + sr * BN + ((c ^ (sr & 7)) << 2));
                 const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
-                *reinterpret_cast<f32x4 *>(obase + (size_t)grow * a.ldo + c * 4) = v;
+                // wave-uniform base + 32-bit byte offset (a tile spans < 4 GB): the store takes its SGPR-base form and the
+                // offset is one add per store instead of a 64-bit multiply-add chain (VALU issue time is matrix-pipe time)
+                const unsigned off = ((unsigned)grow * (unsigned)a.ldo + (unsigned)(c * 4)) * 4u;
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(obase) + off) = v;
             }
             if (j + 1 < TJ) __syncthreads();
         }
