@@ -261,6 +261,19 @@ def test_fused_driver_at_baseline_size_matches_reference(weights0, golden, name)
     rep = {"test": name, "N": N, "H": H, "S": S, "mpjpe_hip": p1, "mpjpe_ref": float(g["mpjpe"]), "pa_hip": p2,
            "pa_ref": float(g["pa_mpjpe"]), "d_mpjpe_mm": abs(p1 - float(g["mpjpe"])) * 1e3,
            "d_pa_mpjpe_mm": abs(p2 - float(g["pa_mpjpe"])) * 1e3}
+    # where do two fp32 runs part ways?  The IPO outcome per (hypothesis, pose) against the reference's own
+    # (rotation angle about z, depth scale), 500 Adam iterations on an L1 loss each
+    R, Tipo, q, sc = zedo_hip.ipo_fit(pipe.x0, pipe.uv, pipe.K, cfg.IPO_keylist, cfg.RotAxes, cfg.IPO_T, cfg.IPO_minScaleT,
+                                      cfg.IPO_maxScaleT, cfg.IPO_iterations, N * len(cfg.IPO_keylist) * 2, H * N,
+                                      return_params=True)
+    ang = torch.atan2(R[:, 1, 0], R[:, 0, 0]).reshape(H, N).cpu().numpy()
+    scl = torch.clamp(sc, cfg.IPO_minScaleT, cfg.IPO_maxScaleT).reshape(H, N).cpu().numpy()
+    da = np.abs((ang - g["ipo_angle"] + np.pi) % (2 * np.pi) - np.pi)
+    ds = np.abs(scl - g["ipo_scale"])
+    rep["ipo_vs_reference"] = dict(angle_rad=dict(median=float(np.median(da)), p90=float(np.percentile(da, 90)),
+                                                  p99=float(np.percentile(da, 99)), within_1e_3=float((da <= 1e-3).mean())),
+                                   depth_scale=dict(median=float(np.median(ds)), p90=float(np.percentile(ds, 90)),
+                                                    p99=float(np.percentile(ds, 99)), within_1e_3=float((ds <= 1e-3).mean())))
     gt = torch.as_tensor(gtc, device="cuda")
     for key, proto in (("p1", False), ("p2", True)):
         err, best, idx = zedo_hip.min_mpjpe(x, gt, N, procrustes=proto)
@@ -268,42 +281,53 @@ def test_fused_driver_at_baseline_size_matches_reference(weights0, golden, name)
         db = best.cpu().numpy() - g[f"best_{key}"]
         de = e - g[f"err_{key}"].astype(np.float64)
         agree = float((idx.cpu().numpy() == g[f"argmin_{key}"]).mean())
-        rep[key] = dict(argmin_agreement=agree, best_delta_mm=dict(
+        rep[key] = dict(argmin_agreement=agree, _best=best.cpu().numpy(), best_delta_mm=dict(
             mean=float(db.mean() * 1e3), std=float(db.std() * 1e3), abs_median=float(np.median(np.abs(db)) * 1e3),
             abs_p90=float(np.percentile(np.abs(db), 90) * 1e3), abs_p99=float(np.percentile(np.abs(db), 99) * 1e3),
             abs_max=float(np.abs(db).max() * 1e3)),
             all_hypotheses_delta_mm=dict(mean=float(de.mean() * 1e3), abs_median=float(np.median(np.abs(de)) * 1e3),
                                          abs_p99=float(np.percentile(np.abs(de), 99) * 1e3)))
     # fp64 arbiter (the reference's loop re-run in float64 on the same inputs, tools/gen_golden.py::..._f64): how far
-    # is the REFERENCE's own fp32 run from exact arithmetic on these dataset means?
+    # is the REFERENCE's own fp32 run from exact arithmetic - per pose and in the dataset means?
     arb = None
     if os.path.exists(os.path.join(ROOT, "tests", "golden", name + "_f64.npz")):
         a = golden(name + "_f64")
         assert str(a["inputs_sha"]) == str(g["inputs_sha"])
-        arb = {"mpjpe_ref64": float(a["mpjpe"]), "pa_ref64": float(a["pa_mpjpe"]),
-               "ref32_vs_ref64_mm": [abs(float(g["mpjpe"]) - float(a["mpjpe"])) * 1e3,
-                                     abs(float(g["pa_mpjpe"]) - float(a["pa_mpjpe"])) * 1e3],
-               "hip_vs_ref64_mm": [abs(p1 - float(a["mpjpe"])) * 1e3, abs(p2 - float(a["pa_mpjpe"])) * 1e3]}
+        arb = {"mpjpe_ref64": float(a["mpjpe"]), "pa_ref64": float(a["pa_mpjpe"])}
+        for key in ("p1", "p2"):
+            d_hip = np.abs(rep[key].pop("_best") - a[f"best_{key}"]) * 1e3          # mm, per pose
+            d_ref = np.abs(g[f"best_{key}"] - a[f"best_{key}"]) * 1e3
+            arb[key] = {"hip_vs_ref64_mm": dict(median=float(np.median(d_hip)), p90=float(np.percentile(d_hip, 90)),
+                                                p99=float(np.percentile(d_hip, 99)), mean=float(d_hip.mean())),
+                        "ref32_vs_ref64_mm": dict(median=float(np.median(d_ref)), p90=float(np.percentile(d_ref, 90)),
+                                                  p99=float(np.percentile(d_ref, 99)), mean=float(d_ref.mean()))}
+        arb["dataset_mean_ref32_vs_ref64_mm"] = [abs(float(g["mpjpe"]) - float(a["mpjpe"])) * 1e3,
+                                                 abs(float(g["pa_mpjpe"]) - float(a["pa_mpjpe"])) * 1e3]
+        arb["dataset_mean_hip_vs_ref64_mm"] = [abs(p1 - float(a["mpjpe"])) * 1e3, abs(p2 - float(a["pa_mpjpe"])) * 1e3]
+    for key in ("p1", "p2"):
+        rep[key].pop("_best", None)
+        rep[key]["standard_error_of_mean_delta_mm"] = rep[key]["best_delta_mm"]["std"] / float(np.sqrt(N))
     rep["arbiter"] = arb
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/parity_report.jsonl", "a") as f:
         f.write(json.dumps(rep) + "\n")
     print(json.dumps(rep))
-    # Bar of BASELINE.json: both dataset means within 0.05 mm of the reference.  The loop is chaotic (per-pose final
-    # errors of two fp32 runs differ by a median 0.1-0.3 mm and by centimetres in the tail, see the report), so a
-    # mean over N poses of a best-of-H carries a sampling error of std(per-pose delta)/sqrt(N); where that alone
-    # exceeds the bar (configs[2], MPJPE without alignment: depth along the ray is weakly constrained) the criterion
-    # is the one of the loop tests: at least as close to the fp64 arbiter as the reference's own fp32 run (x1.5,
-    # + the 0.05 mm bar), and no significant bias (|mean delta| <= 3 standard errors).
+    # Bar of BASELINE.json: both dataset means within 0.05 mm of the reference.  The loop is chaotic with the
+    # random-init fixture weights (per-pose final errors of two fp32 runs differ by a median 0.1-0.3 mm and by
+    # centimetres in the tail, see the report), so a mean over N poses of a best-of-H carries a sampling error of
+    # std(per-pose delta)/sqrt(N); where that alone exceeds the bar (configs[2], MPJPE without alignment: depth along
+    # the ray is weakly constrained) a difference of dataset means says nothing, and the criterion becomes:
+    #   (i)  no significant bias: |mean per-pose delta| <= 3 standard errors;
+    #   (ii) the per-pose deviations from the fp64 arbiter are no larger than the reference's own fp32 run's
+    #        (median and 90th percentile within x1.5 + 0.02 mm) - the criterion of the loop tests, per pose.
     for key, dm in (("p1", rep["d_mpjpe_mm"]), ("p2", rep["d_pa_mpjpe_mm"])):
-        se = rep[key]["best_delta_mm"]["std"] / np.sqrt(N)
-        rep[key]["standard_error_of_mean_delta_mm"] = se
         if dm <= 0.05:
             continue
+        se = rep[key]["standard_error_of_mean_delta_mm"]
         assert abs(rep[key]["best_delta_mm"]["mean"]) <= 3.0 * se, (key, dm, se)
         assert arb is not None, f"{key}: {dm:.3f} mm from the reference and no fp64 arbiter fixture to judge it by"
-        i = 0 if key == "p1" else 1
-        assert arb["hip_vs_ref64_mm"][i] <= 1.5 * arb["ref32_vs_ref64_mm"][i] + 0.05, (key, arb)
+        h, r = arb[key]["hip_vs_ref64_mm"], arb[key]["ref32_vs_ref64_mm"]
+        assert h["median"] <= 1.5 * r["median"] + 0.02 and h["p90"] <= 1.5 * r["p90"] + 0.02, (key, h, r)
 
 
 def test_run_opt_main_and_inference_synthetic(tmp_path):
