@@ -115,6 +115,41 @@ int main(int argc, char **argv) {
         printf("rows %d: one chain %.1f / %.1f us per layer; two half-batch chains on two streams %.1f / %.1f us\n", M, t1, t1b, t2, t2b);
         return 0;
     }
+    if (argc > 2 && atoi(argv[2]) == -3) {   // thin layers: where does the time of pre_dense / post_dense go?  (ablations)
+        float *dxp, *dyp, *dwpre, *dwpost;
+        CK(hipMalloc(&dxp, (size_t)M * 64 * 4)); CK(hipMalloc(&dyp, (size_t)M * 64 * 4));
+        CK(hipMalloc(&dwpre, (size_t)N * 64 * 4)); CK(hipMalloc(&dwpost, (size_t)64 * K * 4));
+        std::vector<float> xp((size_t)M * 64, 0.f), wpre((size_t)N * 64, 0.f), wpost((size_t)64 * K, 0.f);
+        for (int r = 0; r < M; ++r) for (int c = 0; c < 51; ++c) xp[(size_t)r * 64 + c] = u(rng);
+        for (int n = 0; n < N; ++n) for (int c = 0; c < 51; ++c) wpre[(size_t)n * 64 + c] = u(rng) * 0.1f;
+        for (int n = 0; n < 51; ++n) for (int k = 0; k < K; ++k) wpost[(size_t)n * K + k] = u(rng) * 0.03f;
+        CK(hipMemcpy(dxp, xp.data(), xp.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dyp, xp.data(), xp.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dwpre, wpre.data(), wpre.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dwpost, wpost.data(), wpost.size() * 4, hipMemcpyHostToDevice));
+        LayerArgs pre{}; pre.X = dxp; pre.ldx = 64; pre.W = dwpre; pre.ldw = 64; pre.bias = db; pre.gamma = dg; pre.beta = dbe; pre.out = dy; pre.ldo = N;
+        pre.K = 64; pre.N = N; pre.Mp = M; pre.kzero8 = 1;
+        LayerArgs post{}; post.X = dx; post.ldx = K; post.W = dwpost; post.ldw = K; post.bias = db; post.out = dyp; post.ldo = 64; post.K = K; post.N = 64;
+        post.Mp = M; post.sde_a = 1.0001f; post.sde_c = -0.01f;
+        auto timeit = [&](const char *name, auto fn, double flop, double bytes) {
+            for (int r = 0; r < 300; ++r) fn();
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < 200; ++r) fn();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 200;
+            printf("%-74s %7.1f us   %6.1f TF issued   %5.2f TB/s algorithmic\n", name, ms * 1e3, flop / ms / 1e9, bytes / ms / 1e9);
+            return 0;
+        };
+        const double fpre56 = 2.0 * M * 56 * N, fpre64 = 2.0 * M * 64 * N, fpost = 2.0 * M * K * 64;
+        const double bpre = (double)M * (N + 64) * 4, bpost = (double)M * (K + 128) * 4;
+        timeit("pre_dense 64x128 K=56 (product: skips the zero k group) + GN + SiLU", [&] { launch_cfg<64, 128, 2, 4, EPI_GN_SILU, 2, 0, 32, SCHED_THIN, 1, 1>(pre, 0); }, fpre56, bpre);
+        timeit("pre_dense 64x128 K=64 + GN + SiLU", [&] { launch_cfg<64, 128, 2, 4, EPI_GN_SILU, 2, 0, 32, SCHED_THIN>(pre, 0); }, fpre64, bpre);
+        timeit("pre_dense K=56, NO epilogue (MFMA + tile loads only) [ablation]", [&] { launch_cfg<64, 128, 2, 4, EPI_GN_SILU, 2, 2, 32, SCHED_THIN, 1, 1>(pre, 0); }, fpre56, 0);
+        timeit("pre_dense K=56, bias-only epilogue (stores, no GroupNorm / SiLU) [ablation]", [&] { launch_cfg<64, 128, 2, 4, EPI_BIAS, 2, 0, 32, SCHED_THIN, 1, 1>(pre, 0); }, fpre56, bpre);
+        timeit("post_dense 64x64 ring 4 + SDE update (product shape, no reprojection)", [&] { launch_cfg<64, 64, 2, 2, EPI_SDE, 4, 0, 32, SCHED_THIN>(post, 0); }, fpost, bpost);
+        timeit("post_dense, NO epilogue [ablation]", [&] { launch_cfg<64, 64, 2, 2, EPI_SDE, 4, 2, 32, SCHED_THIN>(post, 0); }, fpost, bpost);
+        timeit("post_dense, NO in-loop tile loads (MFMA on stale tiles) [ablation]", [&] { launch_cfg<64, 64, 2, 2, EPI_SDE, 4, 1, 32, 1>(post, 0); }, fpost, 0);
+        timeit("post_dense, neither [ablation]", [&] { launch_cfg<64, 64, 2, 2, EPI_SDE, 4, 3, 32, 1>(post, 0); }, fpost, 0);
+        return 0;
+    }
     // CPU reference (double) for GN+SiLU on a sample of rows spread over the whole batch
     std::vector<int> rows;
     for (int r = 0; r < M; r += 997) rows.push_back(r);
