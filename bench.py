@@ -191,7 +191,7 @@ def main():
                 traffic = tj.get("hidden_dense_bytes_per_launch")
                 mfma_busy = {k: round(v["mfma_util"], 4) for k, v in tj.get("kernels", {}).items()
                              if k.startswith("layer_pair_kernel") and "mfma_util" in v} or None
-            roof = dict(bound="mfma", kernel="zedo::layer_pair_kernel<{GN_SILU|GN_SILU_RES}> (128x128 tiles, 2 workgroups per CU, + 32x128 remainder tiles in the same launch): "
+            roof = dict(bound="mfma", kernel="zedo::layer_pair_kernel<{GN_SILU|GN_SILU_RES}> (128x128 tiles on 16-deep K tiles, 3 workgroups per CU, + 32x128 / 64x128 remainder tiles in the same launch): "
                                              "one 1024x1024 dense layer + GroupNorm + SiLU [+ residual] over all rows",
                         achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,

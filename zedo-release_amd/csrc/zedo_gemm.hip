@@ -37,12 +37,12 @@
 //     behind the barrier that proves every read of tile kt complete (two LDS buffers suffice), one
 //     DMA instruction per four MFMAs over the next two groups instead of a burst: a burst of
 //     8 x 1 KB per wave queues on the CU's 64 B/clk vector-memory path and stalls the wave's MFMA issue.
-//   * Tile shape: 128x128 per workgroup, two workgroups per CU.  One workgroup alone runs its K loop
-//     at ~98 % of the pipe; what the second one buys is cover for prologue and epilogue.  Four waves
-//     (64x64 each) for the plain layers, eight waves (64x32 each, 82 registers, four per SIMD) for
-//     the residual layers, whose epilogue waits on a residual DMA.  Larger tiles (256x128, 256x256),
-//     BK = 16 rings with three or four workgroups per CU and four-fragment-set schedules are in the
-//     ubench variant table below; all measured equal or slower (profiles/ubench_gemm_*).
+//   * Tile shape: 128x128 per workgroup on 16-deep K tiles (64-byte LDS rows, 32 KB ring), THREE workgroups per CU
+//     (round 2; round 1: 32-deep K tiles, two per CU).  One workgroup alone runs its K loop at ~98 % of the pipe; what
+//     the others buy is cover for prologue and epilogue.  Four waves (64x64 each) for the plain layers, eight waves
+//     (64x32 each, 74 registers, six per SIMD) for the residual layers, whose epilogue waits on a residual DMA.
+//     Larger tiles (256x128, 256x256) and four-fragment-set schedules are in the ubench variant table below; all
+//     measured equal or slower (profiles/ubench_gemm_*).
 //   * Tile quantisation: rows that do not fill a whole round of 2 workgroups x 256 CUs run as small
 //     tiles in the SAME launch (layer_pair_kernel): they back-fill CUs as the last big tiles drain.
 //   * Where the remaining ~8 % goes (ablations, profiles/ubench_gemm_49152_r01.txt): no epilogue
@@ -552,15 +552,33 @@ constexpr int SCHED_BIG = ZEDO_SCHED_BIG, SCHED_SMALL = ZEDO_SCHED_SMALL, SCHED_
 #ifndef ZEDO_PLAIN_WPE
 #define ZEDO_PLAIN_WPE 2
 #endif
+// K depth of the big plain tile: 16 (64-byte LDS rows, 32 KB ring: THREE workgroups per CU, 3 waves per SIMD) measured
+// 0.5-0.9 % faster on the plain layers than 32 (two per CU) in the loop (A/B/A/B on one box, 631.7-635.3 vs 634.1-638.4 ms
+// per 200 iterations); the residual layers stay on eight-wave BK = 32 workgroups (82 registers: two per CU).
+#ifndef ZEDO_PAIR_PLAIN_BK
+#define ZEDO_PAIR_PLAIN_BK 16
+#endif
+#ifndef ZEDO_PAIR_PLAIN_SCHED
+#define ZEDO_PAIR_PLAIN_SCHED 1
+#endif
+#ifndef ZEDO_PAIR_RES_BK        // the same for the eight-wave residual tiles (74 registers at 6 waves per SIMD): 0.7 % faster
+#define ZEDO_PAIR_RES_BK 16
+#endif
+#ifndef ZEDO_PAIR_RES_SCHED
+#define ZEDO_PAIR_RES_SCHED 1
+#endif
+#ifndef ZEDO_PAIR_PLAIN_WGS     // workgroups per CU of the plain pair launch: 3, or 4 with the remainder tiles on BK = 16 too [A/B knob]
+#define ZEDO_PAIR_PLAIN_WGS 3
+#endif
 template <int EPI, int W8>
 // (a waves-per-SIMD bound >= 2 also makes hipcc keep the accumulators in VGPRs: no v_accvgpr_read/write, -0.6 %)
-__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : ZEDO_PLAIN_WPE) void layer_pair_kernel(LayerArgs big, LayerArgs small, int nbig) {
+__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? (ZEDO_PAIR_RES_BK == 16 ? 6 : 4) : (ZEDO_PAIR_PLAIN_BK == 16 ? ZEDO_PAIR_PLAIN_WGS : ZEDO_PLAIN_WPE)) void layer_pair_kernel(LayerArgs big, LayerArgs small, int nbig) {
     if constexpr (W8) {
-        if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 4, EPI, 2, 0, 32, SCHED_BIG>(big, blockIdx.x, nbig);
+        if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 4, EPI, 2, 0, ZEDO_PAIR_RES_BK, ZEDO_PAIR_RES_BK == 16 ? ZEDO_PAIR_RES_SCHED : SCHED_BIG>(big, blockIdx.x, nbig);
         else layer_body<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     } else {
-        if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 2, EPI, 2, 0, 32, SCHED_BIG>(big, blockIdx.x, nbig);
-        else layer_body<32, 128, 1, 4, EPI, 2, 0, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+        if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 2, EPI, 2, 0, ZEDO_PAIR_PLAIN_BK, ZEDO_PAIR_PLAIN_SCHED>(big, blockIdx.x, nbig);
+        else layer_body<32, 128, 1, 4, EPI, 2, 0, (ZEDO_PAIR_PLAIN_WGS == 4 ? 16 : 32), SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     }
 }
 
@@ -586,7 +604,10 @@ static int num_cus();
 template <int EPI, int W8>
 static hipError_t launch_pair(const LayerArgs &big, const LayerArgs &small, hipStream_t st) {
     constexpr int SM = W8 ? 64 : 32;                                                    // remainder tile rows
-    constexpr size_t lds = ((size_t)2 * (128 + 128) * 32 + 3 * 128) * sizeof(float);   // the big shape's need covers the small one's
+    constexpr int BKB = W8 ? ZEDO_PAIR_RES_BK : ZEDO_PAIR_PLAIN_BK;
+    constexpr size_t lds_big = ((size_t)2 * (128 + 128) * BKB + 3 * 128) * sizeof(float);
+    constexpr size_t lds_small = ((size_t)2 * ((W8 ? 64 : 32) + 128) * ((!W8 && ZEDO_PAIR_PLAIN_WGS == 4) ? 16 : 32) + 3 * 128) * sizeof(float);
+    constexpr size_t lds = lds_big > lds_small ? lds_big : lds_small;
     if (big.Mp % 128 || small.Mp % SM || big.N % 128 || big.K % 64) return hipErrorInvalidValue;
     auto kern = layer_pair_kernel<EPI, W8>;
     static std::atomic<bool> attr_done[MAX_DEVICES];      // per instantiation and per device
@@ -665,7 +686,8 @@ static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
         if (a.K == 64 && a.kzero8) return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN, 1, 1>(a, st);
         return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);
     }
-    const int per_round = num_cus() * 2 * 128 / (a.N / 128);      // rows covered by one full round of 128x128 tiles, 2 per CU
+    constexpr int WG_PER_CU = (EPI == EPI_GN_SILU_RES ? ZEDO_PAIR_RES_BK : ZEDO_PAIR_PLAIN_BK) == 32 ? 2 : (EPI == EPI_GN_SILU_RES ? 3 : ZEDO_PAIR_PLAIN_WGS);
+    const int per_round = num_cus() * WG_PER_CU * 128 / (a.N / 128);      // rows covered by one full round of 128x128 tiles
     const int rows_big = (a.Mp / per_round) * per_round;
     const int rows_small = a.Mp - rows_big;                       // multiple of 64 (BATCH_PAD)
     static const bool split_launch = getenv("ZEDO_SPLIT_REMAINDER") != nullptr;   // A/B knob: remainder as its own launch
