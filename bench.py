@@ -170,6 +170,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    box_tf = box_ghz = None
+    if rank == 0:
+        box_tf, box_ghz = zh.probe_mfma_peak(200000)      # ~0.2 s, outside the timed region
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         poses_per_s = N_total * a.steps / dt
@@ -195,6 +198,9 @@ def main():
                                              "one 1024x1024 dense layer + GroupNorm + SiLU [+ residual] over all rows",
                         achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+                        # the same kernel against what THIS box's matrix pipe sustains right now (bare MFMA loop)
+                        box_mfma_peak_measured=round(box_tf, 2), box_shader_clock_ghz=round(box_ghz, 3),
+                        frac_of_box_peak=round(ach / box_tf, 4),
                         flop_per_launch=flop_launch, avg_launch_ms=round(hid["avg_ms"], 4),
                         sampled_launches=hid["samples"], launches=hid["launches"],
                         mfma_busy_pmc=mfma_busy,   # SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles

@@ -179,6 +179,11 @@ int zedo_min_mpjpe(const float *d_pred, const double *d_gt, int B, int N, int J,
 #define ZEDO_PROF_REPROJ 3  /* reprojection correction */
 #define ZEDO_PROF_CLASSES 4
 int zedo_profile_start(int sample_every, int max_samples);
+/* What this box's matrix pipe sustains right now: `iters` x 16 back-to-back v_mfma_f32_32x32x2_f32 per wave on every
+ * SIMD (two waves each) -> TFLOP/s, and the shader clock seen over that run.  Boxes of one pool differ by a few per
+ * cent in clock / power state; bench.py reports the dominant kernel against this number next to the datasheet peak.
+ * Synchronises `stream`.  Diagnostic, not part of the data path. */
+int zedo_probe_mfma_peak(int iters, double *h_tflops, double *h_shader_ghz, void *stream);
 int zedo_profile_stop(double *h_total_ms, long long *h_samples, long long *h_launches);
 
 #ifdef __cplusplus

@@ -45,6 +45,8 @@ struct zedo_schedule {
     } while (0)
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static int check_device();
+static int check_device_fwd() { return check_device(); }
 
 // ---- optional sampled kernel timing (diagnostics for bench.py's roofline object) ------------------
 // Every `every`-th launch of a kernel class is bracketed by two hipEvents recorded on the launch stream
@@ -72,6 +74,13 @@ struct ProfScope {
     ~ProfScope() { if (pr) (void)hipEventRecord(pr->b, st); }
 };
 }  // namespace
+
+extern "C" int zedo_probe_mfma_peak(int iters, double *h_tflops, double *h_shader_ghz, void *stream) {
+    if (iters < 1000 || iters > 10000000) return ZEDO_E_BADARG;
+    if (int rc = check_device_fwd()) return rc;
+    HIPCHK(probe_mfma_peak(iters, h_tflops, h_shader_ghz, (hipStream_t)stream));
+    return ZEDO_OK;
+}
 
 extern "C" int zedo_profile_start(int sample_every, int max_samples) {
     if (sample_every < 1 || max_samples < 1) return ZEDO_E_BADARG;

@@ -727,6 +727,52 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
     return hipErrorInvalidValue;
 }
 
+// ---- diagnostic: what this box's matrix pipe sustains right now (clock / power state differ box to box) ----------
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float *out, int iters, long long *clk) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f + 1.0f;
+    long long t0 = 0, w0 = 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { t0 = clock64(); w0 = wall_clock64(); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = clock64() - t0; clk[1] = wall_clock64() - w0; }
+    float s = 0;
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStream_t st) {
+    const int blocks = num_cus() * 2;          // 2 blocks of 4 waves per CU: 2 waves per SIMD, dependent chains hidden
+    float *d_out = nullptr;
+    long long *d_clk = nullptr, clk[2] = {0, 0};
+    hipEvent_t e0, e1;
+    hipError_t e = hipMalloc(&d_out, (size_t)blocks * 256 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&d_clk, 16);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, d_out, iters / 4, d_clk);   // warm the clocks
+    (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, d_out, iters, d_clk);
+    (void)hipEventRecord(e1, st);
+    e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess) e = hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+        const double flop = (double)blocks * 4 * iters * 16 * 2.0 * 32 * 32 * 2;
+        if (tflops) *tflops = flop / ms / 1e9;
+        if (shader_ghz) *shader_ghz = clk[1] > 0 ? (double)clk[0] / ((double)clk[1] / 100e6) / 1e9 : 0.0;   // wall_clock64 ticks at 100 MHz
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d_out); (void)hipFree(d_clk);
+    return e;
+}
+
 #ifdef ZEDO_UBENCH
 // ---- variant table for tools/ubench/ubench_gemm.hip ----
 constexpr int UBENCH_NVAR = 51;

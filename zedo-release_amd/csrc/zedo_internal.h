@@ -45,6 +45,7 @@ struct LayerArgs {
 };
 
 hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st);
+hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStream_t st);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -50,6 +50,7 @@ SIGNATURES = {
                                  _i, _ll, _vp]),
     "zedo_rotate_init": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _vp]),
     "zedo_min_mpjpe": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp]),
+    "zedo_probe_mfma_peak": (_i, [_i, _vp, _vp, _vp]),
     "zedo_profile_start": (_i, [_i, _i]),
     "zedo_profile_stop": (_i, [_vp, _vp, _vp]),
 }
@@ -279,6 +280,14 @@ def min_mpjpe(pred, gt_centred, N, procrustes=False, row_offset=0):
     _check(_lib.zedo_min_mpjpe(_p(pred), _p(gt_centred, torch.float64), B, N, J, int(row_offset), int(bool(procrustes)),
                                _p(err, torch.float64), _p(best, torch.float64), _p(best_h, torch.int32), _stream()))
     return err, best, best_h
+
+
+def probe_mfma_peak(iters=100000):
+    """-> (sustained fp32-MFMA TFLOP/s, shader clock GHz) of this box right now (zedo_probe_mfma_peak)."""
+    _need_gpu()
+    tf, ghz = ctypes.c_double(), ctypes.c_double()
+    _check(_lib.zedo_probe_mfma_peak(int(iters), ctypes.cast(ctypes.byref(tf), _vp), ctypes.cast(ctypes.byref(ghz), _vp), _stream()))
+    return tf.value, ghz.value
 
 
 PROF_CLASSES = ("hidden_dense", "pre_dense", "post_dense_sde", "reproj")
