@@ -778,7 +778,7 @@ hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStr
 constexpr int UBENCH_NVAR = 51;
 static const char *variant_name(int v) {
     switch (v) {
-        case 0: return "product launch_layer (128x128 x2/CU + 32x128 remainder, one launch)";
+        case 0: return "product launch_layer (128x128 BK16 x3/CU + 32x128 remainder, one launch)";
         case 1: return "128x128 4 waves (2x2)";
         case 2: return "256x128 8 waves (4x2)";
         case 3: return "256x256 8 waves (4x2)";
