@@ -817,6 +817,12 @@ def gen_driver_pw3d_full_f64():
                       dtype=torch.float64)
 
 
+def gen_driver_pw3d_full_b():
+    """A second, independent draw of configs[2]'s shape (other poses, other clusters, confidence 1 everywhere): one
+    dataset mean is one sample of a chaotic quantity; a second one tells a bias from a fluctuation."""
+    _driver_full_size("driver_pw3d_full_b", 1015, 50, 1000, 203, 29, list(range(17)), 8.0, 0.2, "ones", "3dpw", CACHE)
+
+
 def gen_driver_pw3d_full():
     """BASELINE configs[2] at its stated size: N = 1015, H = 50, S = 1000, 17-joint key list, IPO_T 8
     (configs/optim/concat_pose_optimization_pw3d.py:72-81), PW3D.eval_multi.  ~45 CPU-minutes: run once
@@ -829,8 +835,9 @@ GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo
             eval=gen_eval, driver=gen_driver, datasets=gen_datasets,
             driver_files=gen_driver_files, samplers=gen_samplers, pc_generic=gen_pc_generic, hp3d_ski=gen_3dhp_ski, driver_full=gen_driver_full,
             driver_h36m_full=gen_driver_h36m_full, driver_pw3d_full=gen_driver_pw3d_full,
-            driver_h36m_full_f64=gen_driver_h36m_full_f64, driver_pw3d_full_f64=gen_driver_pw3d_full_f64)
-SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64"}     # only with --only
+            driver_h36m_full_f64=gen_driver_h36m_full_f64, driver_pw3d_full_f64=gen_driver_pw3d_full_f64,
+            driver_pw3d_full_b=gen_driver_pw3d_full_b)
+SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64", "driver_pw3d_full_b"}     # only with --only
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
