@@ -448,16 +448,9 @@ extern "C" int zedo_ipo_fit_resume(const float *d_x0, const float *d_uv, const f
     if (row_offset + (long long)B > (long long)H * N) return ZEDO_E_BADARG;   // x0[h] would be read out of bounds
     for (int i = 0; i < k; ++i)
         if (h_keylist[i] < 0 || h_keylist[i] >= J) return ZEDO_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
-    int *d_kl = nullptr;
-    HIPCHK(hipMalloc(&d_kl, sizeof(int) * k));
-    hipError_t e = hipMemcpyAsync(d_kl, h_keylist, sizeof(int) * k, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess)
-        e = launch_ipo_fit(d_x0, d_uv, d_K, d_kl, k, axes_mask, ipo_T, min_scale, max_scale, iters, normaliser, d_R, d_T,
-                           d_q, d_scale, d_state, it_begin, B, N, J, row_offset, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);  // d_kl is freed below; h_keylist may be pageable
-    (void)hipFree(d_kl);
-    return (int)e;
+    HIPCHK(launch_ipo_fit(d_x0, d_uv, d_K, h_keylist, k, axes_mask, ipo_T, min_scale, max_scale, iters, normaliser, d_R, d_T,
+                          d_q, d_scale, d_state, it_begin, B, N, J, row_offset, (hipStream_t)stream));
+    return ZEDO_OK;
 }
 
 extern "C" int zedo_ipo_fit(const float *d_x0, const float *d_uv, const float *d_K, const int *h_keylist, int k,

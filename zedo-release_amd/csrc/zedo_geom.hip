@@ -234,8 +234,10 @@ __device__ __forceinline__ float sgnf(float e) { return (e > 0.f) ? 1.f : ((e < 
 constexpr int IPO_TB = 128;
 constexpr int IPO_KMAX = 17;
 
+struct IpoKeys { int j[IPO_KMAX]; };   // IPO_keylist travels as a kernel argument: no device buffer, no sync
+
 __global__ __launch_bounds__(IPO_TB) void ipo_kernel(const float *__restrict__ x0, const float *__restrict__ uv,
-                                                     const float *__restrict__ Kmat, const int *__restrict__ keylist,
+                                                     const float *__restrict__ Kmat, const IpoKeys keylist,
                                                      int k, int axes_mask, float ipo_T, float min_s, float max_s,
                                                      int iters, float inv_norm, float *__restrict__ Rout,
                                                      float *__restrict__ Tout, float *__restrict__ qout,
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(IPO_TB) void ipo_kernel(const float *__restrict__ x
     __shared__ int s_kl[IPO_KMAX];
     const int tid = threadIdx.x;
     const int b = blockIdx.x * IPO_TB + tid;
-    if (tid < k) s_kl[tid] = keylist[tid];
+    if (tid < k) s_kl[tid] = keylist.j[tid];
     __syncthreads();
     if (b >= B) return;
     const long long gb = row_offset + b;
@@ -350,14 +352,16 @@ __global__ __launch_bounds__(IPO_TB) void ipo_kernel(const float *__restrict__ x
     }
 }
 
-hipError_t launch_ipo_fit(const float *x0, const float *uv, const float *K, const int *d_keylist, int k,
+hipError_t launch_ipo_fit(const float *x0, const float *uv, const float *K, const int *h_keylist, int k,
                           int axes_mask, float ipo_T, float min_scale, float max_scale, int iters,
                           double normaliser, float *R, float *T, float *q, float *scale, float *state, int it_begin,
                           int B, int N, int J, long long row_offset, hipStream_t st) {
     if (k < 1 || k > IPO_KMAX) return hipErrorInvalidValue;
     double b1p0 = 1.0, b2p0 = 1.0;
     for (int i = 0; i < it_begin; ++i) { b1p0 *= 0.9; b2p0 *= 0.999; }   // the same running products the kernel forms
-    hipLaunchKernelGGL(ipo_kernel, dim3((B + IPO_TB - 1) / IPO_TB), dim3(IPO_TB), 0, st, x0, uv, K, d_keylist, k,
+    IpoKeys keys{};
+    for (int i = 0; i < k; ++i) keys.j[i] = h_keylist[i];
+    hipLaunchKernelGGL(ipo_kernel, dim3((B + IPO_TB - 1) / IPO_TB), dim3(IPO_TB), 0, st, x0, uv, K, keys, k,
                        axes_mask, ipo_T, min_scale, max_scale, iters, (float)(1.0 / normaliser), R, T, q, scale, state,
                        it_begin, b1p0, b2p0, B, N, J, row_offset);
     return hipGetLastError();
