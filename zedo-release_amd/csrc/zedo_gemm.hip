@@ -197,7 +197,10 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                    // [NBUF][BN][32]  W tile, chunk-swizzled
     float *Bs = smem + NBUF * BN * BK;   // [NBUF][BM][32]  X tile, chunk-swizzled
-    float *Ps = smem + NBUF * (BM + BN) * BK;   // [3][BN]  bias | gamma | beta of this tile's channels (epilogue)
+    // the epilogue stages WM*32 rows x BN channels in the (then free) tile ring; where that is larger than the ring
+    // itself (64-row tiles on a 16-deep ring) the parameter block simply sits behind the larger of the two
+    constexpr int RING_F = NBUF * (BM + BN) * BK, STAGE_F = WM * 32 * BN, BODY_F = RING_F > STAGE_F ? RING_F : STAGE_F;
+    float *Ps = smem + BODY_F;   // [3][BN]  bias | gamma | beta of this tile's channels (epilogue)
 
     // XCD-aware, bijective block -> tile map: the hardware places block b on XCD b % 8; give every
     // XCD a contiguous range of tiles so that the column tiles of one row tile share one L2.
@@ -406,7 +409,7 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
         constexpr int CPRW = BN / 4;         // 16-byte chunks per stage row
         constexpr int RPI = 64 / CPRW;       // stage rows filled by one DMA instruction
         static_assert(CPRW <= 64 && 64 % CPRW == 0 && SR % (RPI * NW) == 0 && (SR * CPRW) % NT == 0, "stage shape");
-        static_assert((size_t)SR * BN <= (size_t)NBUF * (BM + BN) * BK, "stage must fit in the tile buffers");
+        static_assert(SR * BN == STAGE_F, "stage size");
         constexpr bool HAS_RES = (EPI == EPI_GN_SILU_RES || EPI == EPI_SDE);
         float *S = smem;
         float *obase = a.out + (size_t)m0 * a.ldo + n0;
@@ -567,7 +570,7 @@ constexpr int SCHED_BIG = ZEDO_SCHED_BIG, SCHED_SMALL = ZEDO_SCHED_SMALL, SCHED_
 #ifndef ZEDO_PAIR_RES_SCHED
 #define ZEDO_PAIR_RES_SCHED 1
 #endif
-#ifndef ZEDO_PAIR_PLAIN_WGS     // workgroups per CU of the plain pair launch: 3, or 4 with the remainder tiles on BK = 16 too [A/B knob]
+#ifndef ZEDO_PAIR_PLAIN_WGS     // workgroups per CU of the plain pair launch: 3; 4 (64x128 remainder tiles on the BK = 16 ring) measured equal
 #define ZEDO_PAIR_PLAIN_WGS 3
 #endif
 template <int EPI, int W8>
@@ -578,7 +581,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? (ZEDO_PAIR_RES_BK == 16 ? 6 : 
         else layer_body<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     } else {
         if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 2, EPI, 2, 0, ZEDO_PAIR_PLAIN_BK, ZEDO_PAIR_PLAIN_SCHED>(big, blockIdx.x, nbig);
-        else layer_body<32, 128, 1, 4, EPI, 2, 0, (ZEDO_PAIR_PLAIN_WGS == 4 ? 16 : 32), SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+        else if constexpr (ZEDO_PAIR_PLAIN_WGS == 4) layer_body<64, 128, 2, 2, EPI, 2, 0, 16, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+        else layer_body<32, 128, 1, 4, EPI, 2, 0, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     }
 }
 
@@ -603,10 +607,10 @@ static int num_cus();
 
 template <int EPI, int W8>
 static hipError_t launch_pair(const LayerArgs &big, const LayerArgs &small, hipStream_t st) {
-    constexpr int SM = W8 ? 64 : 32;                                                    // remainder tile rows
+    constexpr int SM = (W8 || ZEDO_PAIR_PLAIN_WGS == 4) ? 64 : 32;                      // remainder tile rows
     constexpr int BKB = W8 ? ZEDO_PAIR_RES_BK : ZEDO_PAIR_PLAIN_BK;
     constexpr size_t lds_big = ((size_t)2 * (128 + 128) * BKB + 3 * 128) * sizeof(float);
-    constexpr size_t lds_small = ((size_t)2 * ((W8 ? 64 : 32) + 128) * ((!W8 && ZEDO_PAIR_PLAIN_WGS == 4) ? 16 : 32) + 3 * 128) * sizeof(float);
+    constexpr size_t lds_small = ((!W8 && ZEDO_PAIR_PLAIN_WGS == 4) ? (size_t)64 * 128 + 3 * 128 : (size_t)2 * ((W8 ? 64 : 32) + 128) * 32 + 3 * 128) * sizeof(float);
     constexpr size_t lds = lds_big > lds_small ? lds_big : lds_small;
     if (big.Mp % 128 || small.Mp % SM || big.N % 128 || big.K % 64) return hipErrorInvalidValue;
     auto kern = layer_pair_kernel<EPI, W8>;
@@ -619,7 +623,8 @@ static hipError_t launch_pair(const LayerArgs &big, const LayerArgs &small, hipS
 
 template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1, int KSKIP = 0>
 static hipError_t launch_cfg(const LayerArgs &a, hipStream_t st) {
-    constexpr size_t lds = ((size_t)NBUF * (BM + BN) * BK + 3 * BN) * sizeof(float);
+    constexpr size_t ring_f = (size_t)NBUF * (BM + BN) * BK, stage_f = (size_t)WM * 32 * BN;
+    constexpr size_t lds = ((ring_f > stage_f ? ring_f : stage_f) + 3 * BN) * sizeof(float);
     if (a.Mp <= 0 || a.Mp % BM || a.N % BN || a.K % (BK * NBUF)) return hipErrorInvalidValue;
     if (KSKIP && a.K != BK * NBUF) return hipErrorInvalidValue;
     auto kern = layer_kernel<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, WPE, KSKIP>;
