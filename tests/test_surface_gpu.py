@@ -225,7 +225,7 @@ def _sha(*arrs):
     return h.hexdigest()
 
 
-FULL_SIZE_CAPTURES = [n for n in ("driver_h36m_full", "driver_pw3d_full", "driver_pw3d_full_b")
+FULL_SIZE_CAPTURES = [n for n in ("driver_h36m_full", "driver_pw3d_full", "driver_pw3d_full_b", "driver_pw3d_full_c")
                       if os.path.exists(os.path.join(ROOT, "tests", "golden", n + ".npz"))]
 
 
@@ -331,7 +331,7 @@ def test_fused_driver_at_baseline_size_matches_reference(weights0, golden, name)
         se = rep[key]["standard_error_of_mean_delta_mm"]
         assert abs(rep[key]["best_delta_mm"]["mean"]) <= 3.0 * se, (key, dm, se)
         if arb is None:          # second draw (no float64 run of it): the bias test is what it is there for
-            assert name.endswith("_b"), f"{key}: {dm:.3f} mm from the reference and no fp64 arbiter fixture to judge it by"
+            assert name[-2:] in ("_b", "_c"), f"{key}: {dm:.3f} mm from the reference and no fp64 arbiter fixture to judge it by"
             continue
         h, r = arb[key]["hip_vs_ref64_mm"], arb[key]["ref32_vs_ref64_mm"]
         assert h["median"] <= 1.5 * r["median"] + 0.02 and h["p90"] <= 1.5 * r["p90"] + 0.02, (key, h, r)

@@ -823,6 +823,11 @@ def gen_driver_pw3d_full_b():
     _driver_full_size("driver_pw3d_full_b", 1015, 50, 1000, 203, 29, list(range(17)), 8.0, 0.2, "ones", "3dpw", CACHE)
 
 
+def gen_driver_pw3d_full_c():
+    """Third independent draw (uniform confidences, other seeds)."""
+    _driver_full_size("driver_pw3d_full_c", 1015, 50, 1000, 307, 31, list(range(17)), 8.0, 0.2, "uniform", "3dpw", CACHE)
+
+
 def gen_driver_pw3d_full():
     """BASELINE configs[2] at its stated size: N = 1015, H = 50, S = 1000, 17-joint key list, IPO_T 8
     (configs/optim/concat_pose_optimization_pw3d.py:72-81), PW3D.eval_multi.  ~45 CPU-minutes: run once
@@ -836,8 +841,8 @@ GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo
             driver_files=gen_driver_files, samplers=gen_samplers, pc_generic=gen_pc_generic, hp3d_ski=gen_3dhp_ski, driver_full=gen_driver_full,
             driver_h36m_full=gen_driver_h36m_full, driver_pw3d_full=gen_driver_pw3d_full,
             driver_h36m_full_f64=gen_driver_h36m_full_f64, driver_pw3d_full_f64=gen_driver_pw3d_full_f64,
-            driver_pw3d_full_b=gen_driver_pw3d_full_b)
-SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64", "driver_pw3d_full_b"}     # only with --only
+            driver_pw3d_full_b=gen_driver_pw3d_full_b, driver_pw3d_full_c=gen_driver_pw3d_full_c)
+SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64", "driver_pw3d_full_b", "driver_pw3d_full_c"}     # only with --only
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
