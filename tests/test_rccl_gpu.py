@@ -49,6 +49,16 @@ def test_bench_exchange_step_on_rccl_is_bit_identical():
         out = _run(cmd, dist)
         lines[dist] = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     a, b = lines[False], lines[True]
+    # the bench contract: one JSON line with the driver's keys, the roofline object and the cpu_baseline slot
+    for k, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                   ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                   ("config", dict), ("roofline", dict)):
+        assert isinstance(a[k], typ), (k, a[k])
+    assert a["vs_baseline"] is None and "cpu_baseline" in a and a["scaling"] == "weak" and a["dtype"] == "f32"
+    assert set(a["config"]) >= {"workload"} and not ({"model", "global_batch", "seq_len"} & set(a["config"]))
+    r = a["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert set(r) >= {"traffic", "measured_live", "replayed", "box_mfma_peak_measured", "frac_of_box_peak"}
     assert a["n_gpus"] == b["n_gpus"] == 1
     assert a["selection_sha16"] == b["selection_sha16"], (a["selection_sha16"], b["selection_sha16"])
     assert a["mpjpe_best_of_H_m"] == b["mpjpe_best_of_H_m"] and a["pa_mpjpe_best_of_H_m"] == b["pa_mpjpe_best_of_H_m"]
