@@ -40,7 +40,6 @@ extern "C" {
 #define ZEDO_E_BADARG (-1)      /* NULL pointer, non-positive size, unsupported dimension */
 #define ZEDO_E_NOGPU (-2)       /* no gfx950 device visible */
 #define ZEDO_E_WORKSPACE (-3)   /* workspace smaller than zedo_workspace_bytes() */
-#define ZEDO_E_TIMEOUT (-4)     /* a bounded device-side wait expired (one-launch loop of small batches) */
 
 typedef struct zedo_weights zedo_weights_t;     /* packed ScoreModelFC_Adv parameters on device */
 typedef struct zedo_schedule zedo_schedule_t;   /* per-step tables for one timestamp vector */

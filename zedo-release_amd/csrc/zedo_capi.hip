@@ -35,7 +35,6 @@ struct zedo_weights {
 struct zedo_schedule {
     int S, Sp, nl, hidden;
     float *d_tbias;  // [Sp][NLAYER][H]
-    float *d_ac;     // [2][S]: a then c on the device (the one-launch loop of small batches reads them there)
     std::vector<float> a, c;
 };
 
@@ -138,7 +137,6 @@ extern "C" const char *zedo_error_string(int code) {
         case ZEDO_E_BADARG: return "zedo: bad argument (null pointer, size, or unsupported dimension)";
         case ZEDO_E_NOGPU: return "zedo: no gfx950 device";
         case ZEDO_E_WORKSPACE: return "zedo: workspace too small";
-        case ZEDO_E_TIMEOUT: return "zedo: a bounded device-side wait expired (workgroups of a row tile were not resident together)";
     }
     return code > 0 ? hipGetErrorString((hipError_t)code) : "zedo: unknown error";
 }
@@ -264,10 +262,6 @@ extern "C" int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, i
         if (e == hipSuccess) e = hipMalloc(&d_temb, sizeof(float) * (size_t)Sp * EMB);
     }
     if (e == hipSuccess) e = hipMalloc(&s->d_tbias, sizeof(float) * (size_t)Sp * NLAYER * HID);
-    s->d_ac = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&s->d_ac, sizeof(float) * 2 * (size_t)S);
-    if (e == hipSuccess) e = hipMemcpyAsync(s->d_ac, s->a.data(), sizeof(float) * S, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(s->d_ac + S, s->c.data(), sizeof(float) * S, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_t, h_t, sizeof(float) * S, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = launch_posemb(d_t, S, Sp, label_scale, d_pe, st);
     if (e == hipSuccess) {
@@ -285,7 +279,7 @@ extern "C" int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, i
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);      // h_t may be freed by the caller; the scratch is released
     if (!borrow) { (void)hipFree(d_t); (void)hipFree(d_pe); (void)hipFree(d_temb); }
-    if (e != hipSuccess) { (void)hipFree(s->d_tbias); (void)hipFree(s->d_ac); delete s; return (int)e; }
+    if (e != hipSuccess) { (void)hipFree(s->d_tbias); delete s; return (int)e; }
     *out = s;
     return ZEDO_OK;
 }
@@ -293,7 +287,6 @@ extern "C" int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, i
 extern "C" void zedo_schedule_destroy(zedo_schedule_t *s) {
     if (!s) return;
     (void)hipFree(s->d_tbias);
-    (void)hipFree(s->d_ac);
     delete s;
 }
 
@@ -420,51 +413,6 @@ extern "C" int zedo_oil_run(const zedo_weights_t *w, const zedo_schedule_t *s, f
         const int Bc = (int)std::min(cap, (size_t)B - r0), Bp = round_up(Bc, BATCH_PAD);
         Ws k = carve(d_workspace, B);
         HIPCHK(launch_pack_rows(d_x + r0 * w->J3, k.xpad, Bc, Bp, w->J3, st));
-        // Small batches (ZEDO_CLUSTER_LOOP=1, experimental): the whole loop of the chunk in ONE launch - the workgroups of
-        // a 32-row tile barrier among themselves after every layer instead of five dependent launches per iteration.
-        const bool cluster = getenv("ZEDO_CLUSTER_LOOP") != nullptr;      // read per call: A/B inside one process
-        if (cluster && Bp <= 1024 && step_end > step_begin) {
-            LoopArgs p{};
-            p.W_pre = w->W_pre; p.W_post = w->W_post; p.b_post = w->b_post;
-            for (int l = 0; l < 4; ++l) p.W_hid[l] = w->W_hid[l];
-            for (int l = 0; l < NLAYER; ++l) { p.gamma[l] = w->gamma[l]; p.beta[l] = w->beta[l]; }
-            p.tbias = s->d_tbias; p.sde_a = s->d_ac; p.sde_c = s->d_ac + s->S;
-            p.xpad = k.xpad; p.h = k.h; p.h1 = k.h1; p.geom = d_geom; p.T = d_T + r0 * 3;
-            p.step_begin = step_begin; p.step_end = step_end; p.switch_step = switch_step; p.B = Bc; p.Bp = Bp; p.N = N;
-            p.row0 = row_offset + (long long)r0; p.groups = Bp / 32;
-            unsigned *d_sync = nullptr;
-            HIPCHK(hipMallocAsync((void **)&d_sync, sizeof(unsigned) * (p.groups + 1), st));
-            hipError_t e = hipMemsetAsync(d_sync, 0, sizeof(unsigned) * (p.groups + 1), st);
-            p.sync = d_sync;
-            bool launched = false;
-            if (e == hipSuccess) {
-                ProfScope ps(ZEDO_PROF_REPROJ, st);
-                e = launch_reproj_step_padded(k.xpad, d_geom, d_T + r0 * 3, step_begin >= switch_step, Bc, N, p.row0, st);
-            }
-            if (e == hipSuccess) e = launch_oil_cluster(p, st, &launched);
-            unsigned flag = 0;
-            if (e == hipSuccess && launched) e = hipMemcpyAsync(&flag, d_sync + p.groups, sizeof(unsigned), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess && launched) e = hipStreamSynchronize(st);       // small batches only: one sync per call
-            (void)hipFreeAsync(d_sync, st);
-            HIPCHK(e);
-            if (launched) {
-                if (flag) return ZEDO_E_TIMEOUT;
-                HIPCHK(launch_unpack_rows(k.xpad, d_x + r0 * w->J3, Bc, w->J3, st));
-                continue;
-            }
-            // declined (grid would not be co-resident): the reprojection of the first iteration has run; carry on below
-            for (int i = step_begin; i < step_end; ++i) {
-                NextReproj nr;
-                if (i + 1 < step_end) {
-                    nr.geom = d_geom; nr.T = d_T + r0 * 3; nr.solve = (i + 1) >= switch_step; nr.B = Bc; nr.N = N;
-                    nr.row0 = row_offset + (long long)r0;
-                }
-                HIPCHK(mlp_layers(w, s->d_tbias + (size_t)i * NLAYER * HID, k.xpad, k.h, k.h1, Bp, true, s->a[i], s->c[i],
-                                  nullptr, st, nr));
-            }
-            HIPCHK(launch_unpack_rows(k.xpad, d_x + r0 * w->J3, Bc, w->J3, st));
-            continue;
-        }
         // gradient_field_gen + "denoise_x += joint_gradient" (run/opt_main.py:203-208) of the first iteration; the
         // correction of every later iteration i+1 rides in the epilogue of iteration i's post_dense launch
         // (ZEDO_UNFUSED_REPROJ=1: one launch per iteration, the A/B and parity reference)

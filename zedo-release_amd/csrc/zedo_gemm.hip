@@ -133,7 +133,7 @@ __device__ __forceinline__ void epilogue_values(const f32x16 &acc, const f32x4 (
         }
         float qs = q2.x + q2.y;
         qs += __shfl_xor(qs, 32);
-        const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(qs, 1.0f / 32.0f, 1e-5f));   // one fma, spelled out (-ffp-contract=off)
+        const float rstd = __builtin_amdgcn_rsqf(qs * (1.0f / 32.0f) + 1e-5f);
         const f32x2 r2 = {rstd, rstd}, c2 = {-1.44269504088896340736f, -1.44269504088896340736f}, one2 = {1.0f, 1.0f};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -181,7 +181,7 @@ __device__ long long *g_timeline = nullptr;   // ubench only: 8 x int64 per work
 // tile are known to be zero in both operands and their MFMAs are not issued - pre_dense: K = 51 padded to 64, the
 // group k = 56..63 is padding on both sides; skipping exact zeros leaves every sum bit-identical.
 template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int KSKIP = 0>
-__device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, const int n0) {
+__device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, const int nwg) {
     constexpr int NW = WM * WN;
     constexpr int CPR = BK / 4;                         // 16-byte chunks per tile row (8 or 4)
     constexpr int RPD = 64 / CPR;                       // tile rows moved by one DMA instruction (8 or 16)
@@ -201,6 +201,13 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
     // itself (64-row tiles on a 16-deep ring) the parameter block simply sits behind the larger of the two
     constexpr int RING_F = NBUF * (BM + BN) * BK, STAGE_F = WM * 32 * BN, BODY_F = RING_F > STAGE_F ? RING_F : STAGE_F;
     float *Ps = smem + BODY_F;   // [3][BN]  bias | gamma | beta of this tile's channels (epilogue)
+
+    // XCD-aware, bijective block -> tile map: the hardware places block b on XCD b % 8; give every
+    // XCD a contiguous range of tiles so that the column tiles of one row tile share one L2.
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int ncol = a.N / BN;
+    const int m0 = (lid / ncol) * BM, n0 = (lid % ncol) * BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -450,7 +457,7 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
                     } else if constexpr (EPI == EPI_SDE) {
                         const f32x4 x = *slot;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(a.sde_a, x[e], v[e]);   // x' = a x + [c (eps)]: one fma
+                        for (int e = 0; e < 4; ++e) v[e] += a.sde_a * x[e];
                     }
                     *slot = v;
                 }
@@ -514,17 +521,6 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
         }
     }
 #endif
-}
-
-// One tile per workgroup: block index -> tile.
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int KSKIP = 0>
-__device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, const int nwg) {
-    // XCD-aware, bijective block -> tile map: the hardware places block b on XCD b % 8; give every
-    // XCD a contiguous range of tiles so that the column tiles of one row tile share one L2.
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int ncol = a.N / BN;
-    layer_tile<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP>(a, (lid / ncol) * BM, (lid % ncol) * BN);
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1, int KSKIP = 0>
@@ -734,89 +730,6 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
         case EPI_BIAS_SILU: return launch_wide<EPI_BIAS_SILU>(a, st);
     }
     return hipErrorInvalidValue;
-}
-
-// ---- small batches: the whole OIL loop in one launch ----------------------------------------------------------
-// A batch of up to 1536 rows runs its hidden layers at the compute floor already (896 rows x 1024^2 on 32-row tiles:
-// one wave per SIMD, 13.6 us per layer), and a third of each iteration is spent between its five dependent launches.
-// Here the 16 workgroups owning the 64-channel column tiles of one 32-row tile walk through every layer of every
-// iteration themselves; what a launch boundary did is done by a barrier among those 16 only (rows are independent):
-// arrival counter in global memory, agent-scope release before / acquire after, so that the activations written by
-// the other 15 workgroups (any XCD) are what the next tile's LDS-DMA reads.  All workgroups of a group must be
-// resident at once: the launcher checks the grid against the occupancy of this kernel and declines otherwise; every
-// wait is bounded and raises a flag instead of hanging.  Same layer_tile arithmetic as the per-layer launches: the
-// results are bit-identical.
-constexpr int CL_WG = 16;          // workgroups per row tile (column tiles of 64 channels)
-constexpr int CL_ROWS = 32;
-
-__device__ __forceinline__ void cluster_barrier(unsigned *cnt, unsigned *err, unsigned target) {
-    __threadfence();                       // every wave: its stores are performed at agent scope before the arrival
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-            if (++spins > (1u << 22)) {    // seconds: a partner is not resident (or died) - give up loudly, do not hang
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-    }
-    __syncthreads();
-    __threadfence();                       // acquire for every wave before the next tile's loads
-}
-
-__global__ __launch_bounds__(128, 1) void oil_cluster_kernel(LoopArgs p) {
-    const int g = blockIdx.x / CL_WG, c = blockIdx.x % CL_WG;
-    const int m0 = g * CL_ROWS, n0 = c * 64;
-    unsigned *cnt = p.sync + g, *err = p.sync + p.groups;
-    unsigned phase = 0;
-    for (int i = p.step_begin; i < p.step_end; ++i) {
-        const float *tb = p.tbias + (size_t)i * NLAYER * HID;
-        LayerArgs a{};
-        a.Mp = p.Bp;
-        // pre_dense + GroupNorm + SiLU (model.py:264-269): x -> h
-        a.X = p.xpad; a.ldx = XLD; a.W = p.W_pre; a.ldw = XLD; a.K = XLD; a.N = HID;
-        a.bias = tb; a.gamma = p.gamma[0]; a.beta = p.beta[0]; a.out = p.h; a.ldo = HID; a.kzero8 = 1;
-        layer_tile<CL_ROWS, 64, 1, 2, EPI_GN_SILU, 2, 0, 32, 1, 1>(a, m0, n0);
-        cluster_barrier(cnt, err, ++phase * CL_WG);
-        a.kzero8 = 0; a.ldx = HID; a.ldw = HID; a.K = HID;
-        for (int blk = 0; blk < 2; ++blk) {
-            const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
-            a.X = p.h; a.W = p.W_hid[l1 - 1]; a.bias = tb + (size_t)l1 * HID; a.gamma = p.gamma[l1]; a.beta = p.beta[l1]; a.out = p.h1;
-            layer_tile<CL_ROWS, 64, 1, 2, EPI_GN_SILU, 4, 0, 32, 1>(a, m0, n0);
-            cluster_barrier(cnt, err, ++phase * CL_WG);
-            a.X = p.h1; a.W = p.W_hid[l2 - 1]; a.bias = tb + (size_t)l2 * HID; a.gamma = p.gamma[l2]; a.beta = p.beta[l2]; a.out = p.h;
-            layer_tile<CL_ROWS, 64, 1, 2, EPI_GN_SILU_RES, 4, 0, 32, 1>(a, m0, n0);
-            cluster_barrier(cnt, err, ++phase * CL_WG);
-        }
-        if (c == 0) {      // post_dense + SDE update + the next iteration's reprojection correction: one column tile
-            a.X = p.h; a.W = p.W_post; a.N = XLD; a.bias = p.b_post; a.gamma = a.beta = nullptr; a.out = p.xpad; a.ldo = XLD;
-            a.sde_a = p.sde_a[i]; a.sde_c = p.sde_c[i];
-            if (i + 1 < p.step_end) {
-                a.rp_geom = p.geom; a.rp_T = p.T; a.rp_solve = (i + 1) >= p.switch_step; a.rp_B = p.B; a.rp_N = p.N; a.rp_row0 = p.row0;
-            }
-            layer_tile<CL_ROWS, 64, 1, 2, EPI_SDE, 4, 0, 32, 3>(a, m0, 0);
-        }
-        cluster_barrier(cnt, err, ++phase * CL_WG);
-    }
-}
-
-hipError_t launch_oil_cluster(const LoopArgs &p, hipStream_t st, bool *launched) {
-    *launched = false;
-    constexpr size_t lds = ((size_t)4 * (CL_ROWS + 64) * 32 + 3 * 64) * sizeof(float);   // the 4-slot ring of the K = 1024 tiles
-    if (p.Bp % CL_ROWS || p.groups != p.Bp / CL_ROWS) return hipErrorInvalidValue;
-    int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, oil_cluster_kernel, 128, lds);
-    if (e != hipSuccess) return e;
-    const long long grid = (long long)p.groups * CL_WG;
-    if (grid > (long long)per_cu * num_cus()) return hipSuccess;       // would not be co-resident: decline
-    hipLaunchKernelGGL(oil_cluster_kernel, dim3((unsigned)grid), dim3(128), lds, st, p);
-    e = hipGetLastError();
-    *launched = e == hipSuccess;
-    return e;
 }
 
 // ---- diagnostic: what this box's matrix pipe sustains right now (clock / power state differ box to box) ----------

@@ -47,25 +47,6 @@ struct LayerArgs {
 hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st);
 hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStream_t st);
 
-// The whole OIL loop of a SMALL batch in one launch (zedo_gemm.hip: oil_cluster_kernel): the 16 workgroups that own
-// the 64-channel column tiles of one 32-row tile step through pre_dense, the four hidden layers and post_dense of every
-// iteration with a barrier among themselves after each layer - rows are independent, so no grid-wide barrier exists.
-struct LoopArgs {
-    const float *W_pre, *W_hid[4], *W_post, *b_post;
-    const float *gamma[NLAYER], *beta[NLAYER];
-    const float *tbias;             // [S][NLAYER][HID]
-    const float *sde_a, *sde_c;     // [S], device
-    float *xpad, *h, *h1;           // [Bp][XLD], [Bp][HID] x 2
-    const float *geom;              // [N][17][8]
-    float *T;                       // [B][3]
-    int step_begin, step_end, switch_step, B, Bp, N;
-    long long row0;
-    unsigned *sync;                 // [groups] arrival counters + [1] error flag, zeroed before the launch
-    int groups;
-};
-// launched = false (and hipSuccess): the batch does not fit the co-residency this kernel needs; use the per-layer launches
-hipError_t launch_oil_cluster(const LoopArgs &p, hipStream_t st, bool *launched);
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // geom[n][j] = 8 floats: { r_x, r_y, W, 0,  rhat_x, rhat_y, rhat_z, 0 }   (zedo_reproj_prepare)
