@@ -200,6 +200,12 @@ def main():
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                         # the same kernel against what THIS box's matrix pipe sustains right now (bare MFMA loop)
                         box_mfma_peak_measured=round(box_tf, 2), box_shader_clock_ghz=round(box_ghz, 3),
+                        # the shader clock the sampled launches of THIS kernel really ran at (power management lowers it
+                        # under the full MFMA + LDS + HBM load, by a box-dependent amount) and the fraction of the
+                        # matrix peak AT that clock (157.3 TFLOP/s is quoted at 2.4 GHz)
+                        kernel_shader_clock_ghz=(round(hid["shader_clock_ghz"], 3) if hid.get("shader_clock_ghz") else None),
+                        frac_at_kernel_clock=(round(ach / (PEAK_FP32_MFMA_TFLOPS * hid["shader_clock_ghz"] / 2.4), 4)
+                                              if hid.get("shader_clock_ghz") else None),
                         frac_of_box_peak=round(ach / box_tf, 4),
                         flop_per_launch=flop_launch, avg_launch_ms=round(hid["avg_ms"], 4),
                         sampled_launches=hid["samples"], launches=hid["launches"],

@@ -186,6 +186,9 @@ int zedo_profile_start(int sample_every, int max_samples);
  * Synchronises `stream`.  Diagnostic, not part of the data path. */
 int zedo_probe_mfma_peak(int iters, double *h_tflops, double *h_shader_ghz, void *stream);
 int zedo_profile_stop(double *h_total_ms, long long *h_samples, long long *h_launches);
+/* Shader clock (GHz) the sampled hidden-layer launches of the last profiling session really ran at: shader cycles over
+ * 100 MHz wall ticks, taken by workgroup 0 of each sampled launch around its tile.  0 if nothing was sampled. */
+double zedo_profile_shader_ghz(void);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,9 @@ struct Prof {
     int every = 1;
     struct Pair { hipEvent_t a, b; int cls; };
     std::vector<Pair> pool;
+    long long *d_clk = nullptr;   // [pool.size()][2]: {shader cycles, 100 MHz ticks} of workgroup 0 of a sampled hidden launch
+    size_t clk_cap = 0;
+    double ghz = 0.0;             // result of the last session
     size_t used = 0;
     long long seen[ZEDO_PROF_CLASSES] = {0, 0, 0, 0};
 } g_prof;
@@ -64,9 +67,11 @@ struct Prof {
 struct ProfScope {
     Prof::Pair *pr = nullptr;
     hipStream_t st;
+    long long *clk = nullptr;     // where the sampled launch may drop its clock pair
     ProfScope(int cls, hipStream_t s) : st(s) {
         if (!g_prof.on) return;
         if ((g_prof.seen[cls]++ % g_prof.every) != 0 || g_prof.used >= g_prof.pool.size()) return;
+        if (g_prof.d_clk && g_prof.used < g_prof.clk_cap) clk = g_prof.d_clk + 2 * g_prof.used;
         pr = &g_prof.pool[g_prof.used++];
         pr->cls = cls;
         (void)hipEventRecord(pr->a, st);
@@ -92,12 +97,20 @@ extern "C" int zedo_profile_start(int sample_every, int max_samples) {
             HIPCHK(hipEventCreate(&g_prof.pool[i].b));
         }
     }
+    if (g_prof.clk_cap < g_prof.pool.size()) {
+        (void)hipFree(g_prof.d_clk);
+        g_prof.d_clk = nullptr; g_prof.clk_cap = 0;
+        if (hipMalloc(&g_prof.d_clk, sizeof(long long) * 2 * g_prof.pool.size()) == hipSuccess) g_prof.clk_cap = g_prof.pool.size();
+    }
+    if (g_prof.d_clk) HIPCHK(hipMemset(g_prof.d_clk, 0, sizeof(long long) * 2 * g_prof.clk_cap));
     g_prof.used = 0;
     for (auto &v : g_prof.seen) v = 0;
     g_prof.every = sample_every;
     g_prof.on = true;
     return ZEDO_OK;
 }
+
+extern "C" double zedo_profile_shader_ghz(void) { return g_prof.ghz; }
 
 extern "C" int zedo_profile_stop(double *h_total_ms, long long *h_samples, long long *h_launches) {
     g_prof.on = false;
@@ -109,6 +122,14 @@ extern "C" int zedo_profile_stop(double *h_total_ms, long long *h_samples, long 
         HIPCHK(hipEventElapsedTime(&ms, g_prof.pool[i].a, g_prof.pool[i].b));
         tot[g_prof.pool[i].cls] += ms;
         cnt[g_prof.pool[i].cls] += 1;
+    }
+    g_prof.ghz = 0.0;
+    if (g_prof.d_clk && g_prof.used) {
+        std::vector<long long> ck(2 * g_prof.used);
+        HIPCHK(hipMemcpy(ck.data(), g_prof.d_clk, sizeof(long long) * ck.size(), hipMemcpyDeviceToHost));
+        double cyc = 0, ticks = 0;
+        for (size_t i = 0; i < g_prof.used; ++i) if (ck[2 * i + 1] > 0) { cyc += (double)ck[2 * i]; ticks += (double)ck[2 * i + 1]; }
+        if (ticks > 0) g_prof.ghz = cyc / (ticks / 100e6) / 1e9;
     }
     for (int c = 0; c < ZEDO_PROF_CLASSES; ++c) {
         if (h_total_ms) h_total_ms[c] = tot[c];
@@ -343,11 +364,11 @@ static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad
         const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
         a.X = h; a.ldx = HID; a.W = w->W_hid[l1 - 1]; a.ldw = HID; a.K = HID; a.N = HID;
         a.bias = tb + (size_t)l1 * HID; a.gamma = w->gamma[l1]; a.beta = w->beta[l1]; a.out = h1; a.ldo = HID;
-        { ProfScope ps(ZEDO_PROF_HIDDEN, st); e = launch_layer(a, EPI_GN_SILU, st); }
+        { ProfScope ps(ZEDO_PROF_HIDDEN, st); a.clk = ps.clk; e = launch_layer(a, EPI_GN_SILU, st); a.clk = nullptr; }
         if (e != hipSuccess) break;
         a.X = h1; a.W = w->W_hid[l2 - 1];
         a.bias = tb + (size_t)l2 * HID; a.gamma = w->gamma[l2]; a.beta = w->beta[l2]; a.out = h;  // h = h + h2, in place
-        { ProfScope ps(ZEDO_PROF_HIDDEN, st); e = launch_layer(a, EPI_GN_SILU_RES, st); }
+        { ProfScope ps(ZEDO_PROF_HIDDEN, st); a.clk = ps.clk; e = launch_layer(a, EPI_GN_SILU_RES, st); a.clk = nullptr; }
     }
     if (e != hipSuccess) return e;
     a.X = h; a.ldx = HID; a.W = w->W_post; a.ldw = HID; a.K = HID; a.N = XLD; a.bias = w->b_post;

@@ -580,6 +580,10 @@ constexpr int SCHED_BIG = ZEDO_SCHED_BIG, SCHED_SMALL = ZEDO_SCHED_SMALL, SCHED_
 template <int EPI, int W8>
 // (a waves-per-SIMD bound >= 2 also makes hipcc keep the accumulators in VGPRs: no v_accvgpr_read/write, -0.6 %)
 __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? (ZEDO_PAIR_RES_BK == 16 ? 6 : 4) : (ZEDO_PAIR_PLAIN_BK == 16 ? ZEDO_PAIR_PLAIN_WGS : ZEDO_PLAIN_WPE)) void layer_pair_kernel(LayerArgs big, LayerArgs small, int nbig) {
+    // diagnostic: the shader clock this launch really runs at (power management differs box to box and with the load)
+    long long c0 = 0, w0 = 0;
+    const bool probe = big.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    if (probe) { c0 = clock64(); w0 = wall_clock64(); }
     if constexpr (W8) {
         if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 4, EPI, 2, 0, ZEDO_PAIR_RES_BK, ZEDO_PAIR_RES_BK == 16 ? ZEDO_PAIR_RES_SCHED : SCHED_BIG>(big, blockIdx.x, nbig);
         else layer_body<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
@@ -588,6 +592,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? (ZEDO_PAIR_RES_BK == 16 ? 6 : 
         else if constexpr (ZEDO_PAIR_PLAIN_WGS == 4) layer_body<64, 128, 2, 2, EPI, 2, 0, 16, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
         else layer_body<32, 128, 1, 4, EPI, 2, 0, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     }
+    if (probe) { big.clk[0] = clock64() - c0; big.clk[1] = wall_clock64() - w0; }
 }
 
 // Per-device launch state.  The dense kernels ask for 67-83 KB of dynamic LDS (above the 64 KB default), which must

@@ -35,6 +35,7 @@ struct LayerArgs {
     int Mp;              // multiple of the tile's BM
     float sde_a, sde_c;  // EPI_SDE
     int kzero8;          // K == 64 only: columns k = 56..63 of X and W are zero padding (their MFMAs are skipped)
+    long long *clk;      // diagnostic (may be null): workgroup 0 writes {shader cycles, 100 MHz wall ticks} it spent in the tile
     // EPI_SDE only, optional (rp_geom != nullptr): the reprojection correction of the NEXT loop iteration
     // (gradient_field_gen + "denoise_x += joint_gradient", run/opt_main.py:203-208) applied to the freshly updated rows
     // while they are still in LDS, instead of a separate launch that reads and rewrites them.

@@ -53,6 +53,7 @@ SIGNATURES = {
     "zedo_probe_mfma_peak": (_i, [_i, _vp, _vp, _vp]),
     "zedo_profile_start": (_i, [_i, _i]),
     "zedo_profile_stop": (_i, [_vp, _vp, _vp]),
+    "zedo_profile_shader_ghz": (_d, []),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = library/header mismatch: fail loudly
@@ -304,5 +305,7 @@ def profile_stop():
     cnt = (ctypes.c_longlong * n)()
     seen = (ctypes.c_longlong * n)()
     _check(_lib.zedo_profile_stop(ctypes.cast(tot, _vp), ctypes.cast(cnt, _vp), ctypes.cast(seen, _vp)))
-    return {k: dict(total_ms=tot[i], samples=int(cnt[i]), launches=int(seen[i]),
-                    avg_ms=(tot[i] / cnt[i] if cnt[i] else None)) for i, k in enumerate(PROF_CLASSES)}
+    out = {k: dict(total_ms=tot[i], samples=int(cnt[i]), launches=int(seen[i]),
+                   avg_ms=(tot[i] / cnt[i] if cnt[i] else None)) for i, k in enumerate(PROF_CLASSES)}
+    out["hidden_dense"]["shader_clock_ghz"] = float(_lib.zedo_profile_shader_ghz()) or None
+    return out
