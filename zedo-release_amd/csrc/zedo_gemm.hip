@@ -582,7 +582,11 @@ template <int EPI, int W8>
 __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? (ZEDO_PAIR_RES_BK == 16 ? 6 : 4) : (ZEDO_PAIR_PLAIN_BK == 16 ? ZEDO_PAIR_PLAIN_WGS : ZEDO_PLAIN_WPE)) void layer_pair_kernel(LayerArgs big, LayerArgs small, int nbig) {
     // diagnostic: the shader clock this launch really runs at (power management differs box to box and with the load)
     long long c0 = 0, w0 = 0;
+#ifdef ZEDO_NO_CLKPROBE
+    const bool probe = false;
+#else
     const bool probe = big.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+#endif
     if (probe) { c0 = clock64(); w0 = wall_clock64(); }
     if constexpr (W8) {
         if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 4, EPI, 2, 0, ZEDO_PAIR_RES_BK, ZEDO_PAIR_RES_BK == 16 ? ZEDO_PAIR_RES_SCHED : SCHED_BIG>(big, blockIdx.x, nbig);
