@@ -7,6 +7,18 @@ resident in HBM when the timed region starts.  `value` = poses fully processed p
 ranks (N * n_gpus * steps / time); for --gpus > 1 (weak scaling: 1015 poses per GPU) the H*N_total rows are
 sharded contiguously over the ranks and the per-pose minimum is combined with one RCCL MIN all-reduce.
 
+Launch forms (both give ONE JSON line from rank 0 with n_gpus = rccl_ranks = number of ranks):
+  python bench.py --gpus N ...                          the parent - before ANY GPU call - starts N fresh child processes
+                                                        (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), one per GPU, and
+                                                        exits non-zero if any of them fails;
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (ranks from the environment).
+--scaling weak (default): --poses per GPU;  --scaling strong: --poses in total, rows sharded over the ranks.
+--workload 2 (default) BASELINE configs[2]: 3DPW settings, 1015 poses x H=50, P1+P2 selection (MIN all-reduce);
+           3 configs[3]: H36M settings, the full test set (567 040 poses) x H=50, action-wise selection - strong by
+             definition (weak: 70 880 poses per GPU);
+           4 configs[4]: run.inference without --eval on 100 000 detections x H=50: no selection, the one exchange is
+             the all-gather of every hypothesis of every pose (weak: 12 500 poses per GPU).
+
 The JSON line also carries
   roofline     : the dominant kernel (the four 1024x1024 fp32-MFMA dense layers): algorithmic FLOP per launch
                  / its average launch duration, measured live with sampled HIP events on the launch stream;
@@ -32,10 +44,24 @@ FLOP_PER_ROW_STEP = 2 * (51 * 1024 + 4 * 1024 * 1024 + 1024 * 51)   # 8 597 504 
 PEAK_FP32_MFMA_TFLOPS = 157.3                                        # MI355X_MICROARCH.md
 
 
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(weights, cfg_kw, seed):
-    """CPU port of the reference path on the host cores: IPO at the reference batch size (numpy oracle) + a bounded
-    number of OIL steps with the multi-threaded port (torch CPU operators = what the reference runs on a CPU),
-    extrapolated per pose-hypothesis.  Test infrastructure used only as a baseline."""
+    """CPU port of the reference path (run/opt_main.py:166-228) on the host cores: one hypothesis slice of the reference
+    batch (1015 poses): IPO 500 iterations (numpy oracle) + a slice of the OIL loop that crosses the switch to the
+    least-squares T at the loop's own 1/5 point (torch CPU operators = what the reference itself runs on a CPU) + the
+    P1 / P2 metric, extrapolated per pose-hypothesis to S = 1000 and H = 50.  Timed at the fastest thread count the box
+    offers AND on one thread.  Test infrastructure used only as a baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import zedo_oracle as O
     import zedo_oracle_mt as M
@@ -44,7 +70,7 @@ def cpu_baseline(weights, cfg_kw, seed):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    n, steps = N_POSES, 30
+    n, steps, steps_1t = N_POSES, 120, 15
     d = syn.make_poses(n, seed=seed)
     cl = syn.make_clusters(1, seed=seed)
     cond, K = d["db_2d"][:, :, :2], d["camera_param"]
@@ -55,10 +81,12 @@ def cpu_baseline(weights, cfg_kw, seed):
     R, T, _, _, _ = O.ipo_fit(x0[:, kl], T0, K, cond[:, kl], "z", 0.2, 2.0, 500)
     t_ipo = time.perf_counter() - t0
     port = M.StepPort(weights, cond, K, d["db_2d"][:, :, 2].copy())
-    x, Tt = torch.tensor(np.einsum("bij,bkj->bki", R, x0).astype(np.float32)), torch.tensor(T.astype(np.float32))
+    x_init = torch.tensor(np.einsum("bij,bkj->bki", R, x0).astype(np.float32))
+    T_init = torch.tensor(T.astype(np.float32))
     ts = O.oil_timestamps(S_OIL)
     # thread count: more is not faster for [1015 x 1024] operands (256 threads: 5.8 s per step on the GPU box);
     # double from 8 while a step gets faster, keep the best
+    x, Tt = x_init, T_init
     cores, best = 1, float("inf")
     for th in [c for c in (8, 16, 32, 64, 128, 256) if c <= avail] or [avail]:
         torch.set_num_threads(th)
@@ -71,21 +99,41 @@ def cpu_baseline(weights, cfg_kw, seed):
             cores, best = th, dt
         if dt > 1.5 * best:
             break
+
+    def oil_slice(nsteps):       # the first 1/5 with the IPO's T, the rest with the least-squares T, like the loop itself
+        x, Tt = x_init, T_init
+        port.step(x, Tt, ts[0], False)
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            x, Tt = port.step(x, Tt, ts[i * (S_OIL // nsteps)], i >= nsteps // 5)
+        return (time.perf_counter() - t0) / nsteps, x
+
     torch.set_num_threads(cores)
-    port.step(x, Tt, ts[0], False)
-    t0 = time.perf_counter()
-    for i in range(steps):   # a fifth with the given T, the rest with the least-squares T, as in the real loop
-        x, Tt = port.step(x, Tt, ts[i], i >= steps // 5)
-    t_step = (time.perf_counter() - t0) / steps
+    t_step, x = oil_slice(steps)
+    torch.set_num_threads(1)
+    t_step_1t, _ = oil_slice(steps_1t)
+    torch.set_num_threads(cores)
     gt = d["db_3d"] - d["db_3d"][:, 0:1]
     t0 = time.perf_counter()
     O.hypothesis_errors(x.numpy()[:, None], gt, False)
     O.hypothesis_errors(x.numpy()[:, None], gt, True)
     t_eval = time.perf_counter() - t0
     per_pose_hyp = (t_ipo + S_OIL * t_step + t_eval) / n
+    per_pose_hyp_1t = (t_ipo + S_OIL * t_step_1t + t_eval) / n
     return dict(value=1.0 / (N_HYPO * per_pose_hyp), unit="poses/s", cores=int(cores), kind="port",
-                sample=f"CPU port (oracle/), {n} poses x 1 hypothesis: IPO 500 it, numpy ({t_ipo:.1f} s) + {steps} of {S_OIL} "
-                       f"OIL steps, torch CPU operators on {cores} of {avail} usable threads - the fastest count ({t_step * 1e3:.1f} ms/step) + P1/P2 metric, "
+                cpu_model=cpu_model_name(), threads_available=int(avail),
+                one_thread=dict(value=1.0 / (N_HYPO * per_pose_hyp_1t), unit="poses/s", cores=1,
+                                ms_per_step=round(t_step_1t * 1e3, 1), steps_timed=steps_1t),
+                ms_per_step=round(t_step * 1e3, 2), steps_timed=steps, ipo_s=round(t_ipo, 2), metric_s=round(t_eval, 2),
+                # the reference itself (its own modules imported on CPU) could only be timed in the build container
+                # (8-core Xeon @ 2.10 GHz): 0.40-0.43 poses/s at H=50, S=1000 on 8 threads,
+                # 5 862 pose-steps/s = 0.117 poses/s on one thread; this port measured 0.41 there
+                reference_in_build_container=dict(value=[0.40, 0.43], unit="poses/s", cores=8, one_thread_value=0.117,
+                                                  cpu_model="Intel Xeon @ 2.10 GHz (8 cores)", source="BASELINE.md section 2"),
+                sample=f"CPU port (oracle/), one hypothesis slice of {n} poses: IPO 500 it, numpy ({t_ipo:.1f} s) + {steps} OIL steps "
+                       f"spread over the {S_OIL}-step schedule, the first {steps // 5} with the IPO's T and the rest with the "
+                       f"least-squares T (torch CPU operators on {cores} of {avail} usable threads - the fastest count: "
+                       f"{t_step * 1e3:.1f} ms/step; one thread: {t_step_1t * 1e3:.0f} ms/step over {steps_1t} steps) + P1/P2 metric, "
                        f"extrapolated to H={N_HYPO}, S={S_OIL}")
 
 
@@ -100,20 +148,102 @@ def selection_digest(out):
     return h.hexdigest()[:16]
 
 
+WORKLOADS = {
+    # poses = the configuration's TOTAL pose count; weak scaling gives every GPU `weak` poses instead
+    2: dict(name="BASELINE configs[2] (3DPW pw3d_test, H=50, 1000 steps)", settings="pw3d", poses=1015, weak=1015,
+            select="p1p2", default_scaling="weak"),
+    3: dict(name="BASELINE configs[3] (H36M full test set = ZeDO.sample 1: 567 040 poses, H=50)", settings="h36m", poses=567040,
+            weak=70880, select="h36m", default_scaling="strong"),
+    4: dict(name="BASELINE configs[4] (run.inference, 100 000 synthetic 2D detections, H=50, no --eval)", settings="h36m",
+            poses=100000, weak=12500, select="gather", default_scaling="strong"),
+}
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def rank_environments(n, port, base=None):
+    """Environment of each of the n ranks the launcher starts (one process per GPU, RCCL rendezvous on 127.0.0.1)."""
+    envs = []
+    for r in range(n):
+        e = dict(os.environ if base is None else base)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC
+        envs.append(e)
+    return envs
+
+
+def launch_ranks(n, argv, dry=False):
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh processes, one per GPU.  The parent makes
+    NO GPU call (device_count() does not initialise the runtime), so every child starts from a clean process; a failing
+    rank ends the others and the parent exits with its code."""
+    import subprocess
+    visible = torch.cuda.device_count()
+    port = free_port()
+    envs = rank_environments(n, port)
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv
+    if dry:
+        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")
+        print(json.dumps({"dry_launch": True, "gpus": n, "visible_gpus": visible, "cmd": cmd,
+                          "ranks": [{k: e[k] for k in keys} for e in envs]}), flush=True)
+        return 0
+    if visible < n:
+        print(f"bench.py: --gpus {n} but only {visible} GPU(s) are visible", file=sys.stderr)
+        return 2
+    procs = [subprocess.Popen(cmd, env=e) for e in envs]
+    rc = 0
+    try:
+        live = set(range(n))
+        while live and rc == 0:
+            time.sleep(0.2)
+            for r in sorted(live):
+                c = procs[r].poll()
+                if c is not None:
+                    live.discard(r)
+                    if c != 0:
+                        print(f"bench.py: rank {r} exited with code {c}", file=sys.stderr)
+                        rc = c if c > 0 else 1
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        for pr in procs:
+            try:
+                pr.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--poses", type=int, default=N_POSES, help="poses per GPU (default: BASELINE configs[2])")
+    ap.add_argument("--workload", type=int, default=2, choices=sorted(WORKLOADS), help="BASELINE.json configs[i]")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="weak: --poses per GPU (default for workload 2); strong: --poses in total (default for 3, 4)")
+    ap.add_argument("--poses", type=int, default=None, help="override the workload's pose count (per GPU if weak, total if strong)")
     ap.add_argument("--hypo", type=int, default=N_HYPO)
     ap.add_argument("--oil", type=int, default=S_OIL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-launch", action="store_true", help="print the rank environments the launcher would start, and exit")
     a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.dry_launch):
+        sys.exit(launch_ranks(a.gpus, [x for x in sys.argv[1:] if x != "--dry-launch"], dry=a.dry_launch))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -127,26 +257,43 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     import zedo_hip as zh
-    from zedo_hip.pipeline import Pipeline, ZeDOConfig, reduce_min_over_ranks, shard_rows
+    from zedo_hip.pipeline import Pipeline, ZeDOConfig, gather_row_shards, reduce_min_over_ranks, shard_rows
     from lib.dataset import synthetic as syn
 
     # ---- synthetic problem: every rank builds the same global problem, processes its own row shard
-    N_total, H, S = a.poses * world, a.hypo, a.oil
+    wl = WORKLOADS[a.workload]
+    scaling = a.scaling or wl["default_scaling"]
+    per = a.poses if a.poses is not None else (wl["weak"] if scaling == "weak" else wl["poses"])
+    N_total = per * world if scaling == "weak" else per
+    H, S = a.hypo, a.oil
+    stated = (a.poses is None and H == N_HYPO and S == S_OIL)
     weights = syn.make_weights(seed=0)
-    d = syn.make_poses(N_total, seed=2024)
+    h36m = wl["settings"] == "h36m"
+    d = syn.make_poses(N_total, seed=2024, dtype3d=np.float64 if (h36m and wl["select"] == "h36m") else np.float32)
     clusters = syn.make_clusters(H, seed=2024)
-    cfg = ZeDOConfig.pw3d(OIL_iterations=S)
+    cfg = (ZeDOConfig.h36m if h36m else ZeDOConfig.pw3d)(OIL_iterations=S)
     pipe = Pipeline(weights, cfg, dev).load(clusters, d["db_2d"], d["camera_param"])
-    gt = (d["db_3d"] - d["db_3d"][:, 0:1]).astype(np.float64)
-    gt_dev = torch.tensor(gt, dtype=torch.float64, device=dev)
+    if wl["select"] == "h36m":          # millimetre float64 ground truth, centred the way h36m.py:400-401 does
+        mm = d["db_3d"] * 1000.0
+        gt = (mm - mm[:, 0:1]) / 1000.0
+        actions = 2 + (np.arange(N_total) % 15)
+    else:
+        gt = (d["db_3d"] - d["db_3d"][:, 0:1]).astype(np.float64)
+    gt_dev = torch.tensor(gt, dtype=torch.float64, device=dev) if wl["select"] != "gather" else None
     lo, rows = shard_rows(H * N_total, rank, world)
 
     def one_pass():
         x, T = pipe.run(row_offset=lo, rows=rows)
+        if wl["select"] == "gather":     # run/inference.py:233-236: every hypothesis of every pose, on every rank
+            return x, {"results": gather_row_shards(x, H * N_total)}
         sel = pipe.select(x, gt_dev, row_offset=lo)
         out = {}
         for k, (best, idx) in sel.items():
             out[k] = reduce_min_over_ranks(best, idx)
+        if wl["select"] == "h36m":       # action-wise mean of means (h36m.py:424-433) on the host, like eval_multi
+            for k in ("p1", "p2"):
+                b = out[k][0].cpu().numpy()
+                out[k + "_actionwise"] = float(np.mean([b[actions == act].mean() for act in range(2, 17)]))
         return x, out
 
     def fence():
@@ -189,7 +336,7 @@ def main():
             tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC pass, collected separately
             mfma_busy = None
             tj = {}
-            if os.path.exists(tp):
+            if os.path.exists(tp) and rows == N_POSES * N_HYPO:   # the counter pass was collected on this launch shape
                 tj = json.load(open(tp))
                 traffic = tj.get("hidden_dense_bytes_per_launch")
                 mfma_busy = {k: round(v["mfma_util"], 4) for k, v in tj.get("kernels", {}).items()
@@ -216,23 +363,37 @@ def main():
                         replayed={"fields": ["traffic", "mfma_busy_pmc"],
                                   "source": "profiles/hbm_traffic.json" if traffic is not None else None,
                                   "collected": tj.get("collected") if traffic is not None else None})
+        if wl["select"] == "gather":
+            res = out["results"]
+            quality = {"results_shape": [int(v) for v in res.shape], "results_finite": bool(torch.isfinite(res).all().item()),
+                       "results_sha16": __import__("hashlib").sha256(res[:: max(1, res.shape[0] // 4096)].cpu().numpy().tobytes()).hexdigest()[:16]}
+        else:
+            quality = {"mpjpe_best_of_H_m": round(float(out["p1"][0].mean().item()), 6),
+                       "pa_mpjpe_best_of_H_m": round(float(out["p2"][0].mean().item()), 6),
+                       "selection_sha16": selection_digest(out)}
+            if wl["select"] == "h36m":
+                quality["mpjpe_actionwise_m"] = round(out["p1_actionwise"], 6)
+                quality["pa_mpjpe_actionwise_m"] = round(out["p2_actionwise"], 6)
+        what = {"p1p2": "P1/P2 min-over-hypotheses selection", "h36m": "action-wise P1/P2 min-over-hypotheses selection",
+                "gather": "all-gather of every hypothesis of every pose (results resident on every rank; the D2H copy + np.save "
+                          "of run/inference.py:236 are file I/O outside the path)"}[wl["select"]]
         line = {
             "metric": "poses/sec (1000-step sampler, H=50)", "value": round(poses_per_s, 3), "unit": "poses/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[2] shape (3DPW)" if (a.poses, H, S) == (N_POSES, N_HYPO, S_OIL)
-                                    else "3DPW settings, non-default size") + f": N={a.poses} poses/GPU x H={H} hypotheses, "
-                                   f"IPO 500 it (17 joints) + {S} OIL steps + P1/P2 min-over-hypotheses selection; "
+            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if use_dist else 1),
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (wl["name"] if stated else wl["name"] + " - NON-STATED size") +
+                                   f": N={per} poses{'/GPU' if scaling == 'weak' else ' in total'} x H={H} hypotheses, "
+                                   f"IPO 500 it ({len(cfg.IPO_keylist)} joints) + {S} OIL steps + {what}; "
                                    "random-init ScoreModelFC_Adv weights, synthetic detections",
+                       "baseline_config": a.workload, "settings": wl["settings"],
                        "rows_per_gpu": rows, "poses_total": N_total, "sharding": f"rows over {world} rank(s)"},
             "pose_hyp_steps_per_s": round(row_steps_per_s, 1),
             "end_to_end_tflops": round(row_steps_per_s * FLOP_PER_ROW_STEP / 1e12, 2),
             # all six layers' algorithmic FLOP over the wall time of the whole pass (IPO, reprojection, selection,
             # launch gaps included) against the same fp32-MFMA peak
-            "end_to_end_frac": round(row_steps_per_s * FLOP_PER_ROW_STEP / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-            "mpjpe_best_of_H_m": round(float(out["p1"][0].mean().item()), 6),
-            "pa_mpjpe_best_of_H_m": round(float(out["p2"][0].mean().item()), 6),
-            "selection_sha16": selection_digest(out),
+            "end_to_end_frac": round(row_steps_per_s * FLOP_PER_ROW_STEP / 1e12 / PEAK_FP32_MFMA_TFLOPS / world, 4),
+            **quality,
             "roofline": roof,
             "kernel_time_ms_sampled_avg": {k: (round(v["avg_ms"], 4) if v["avg_ms"] else None) for k, v in prof.items()},
         }

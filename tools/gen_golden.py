@@ -43,7 +43,7 @@ from lib.dataset.pw3d import PW3D
 from lib.utils.transforms import procrustes
 
 OUT = os.path.join(ROOT, "tests", "golden")
-torch.set_num_threads(8)
+torch.set_num_threads(int(os.environ.get("ZEDO_GOLDEN_THREADS", "8")))
 
 
 def ref_config():
@@ -835,14 +835,103 @@ def gen_driver_pw3d_full():
     _driver_full_size("driver_pw3d_full", 1015, 50, 1000, 103, 19, list(range(17)), 8.0, 0.2, "uniform", "3dpw", CACHE)
 
 
+def _driver_ipo_pin(tag, N, H, seed_pose, seed_cl, keylist, ipo_T, minT, conf_mode, dataset, cache_dir):
+    """SURVEY 7 parity stage (A) at BASELINE size: the reference's own IPO OUTPUT of the run captured by
+    _driver_full_size(tag, ...) - per (hypothesis, pose) the rotation about z as (cos, sin) = (R[0,0], R[1,0]) exactly as
+    RotOpt.generate_matrix() returned it (the other entries of R are exact 0 / 1 / copies: asserted) and
+    T = T0 * clamp(scale) (opt_main.py:194-195), both float32 - so that the OIL loop can be run from the REFERENCE's
+    (R, T) and compared with the reference's final poses without the IPO's chaotic last iterate in between.
+    Read from the per-hypothesis cache of the full capture; a missing cache entry re-runs the (deterministic) IPO."""
+    d = syn.make_poses(N, seed=seed_pose, conf_mode=conf_mode, dtype3d=np.float64 if dataset == "h36m" else np.float32)
+    cl = syn.make_clusters(H, seed=seed_cl)
+    gt_2d, K = d["db_2d"], d["camera_param"]
+    full = np.load(os.path.join(OUT, tag + ".npz"))
+    assert str(full["inputs_sha"]) == _sha(gt_2d, K, cl)
+    cs, Ts = [], []
+    for sid in range(H):
+        f = os.path.join(cache_dir, f"{tag}_h{sid:02d}.npz")
+        if os.path.exists(f):
+            z = np.load(f)
+            R, Tf = z["R"], z["T"]
+        else:
+            noisy = (torch.ones((N, 17, 3)) * torch.tensor(cl - cl[:, 0:1, :])[sid:sid + 1])
+            r = run_ref_ipo(noisy.numpy(), gt_2d[:, :, :2], K, "z", keylist, ipo_T, minT, 2.0, 500, trace_upto=1)
+            R, Tf = r["R"], r["T"]
+        assert R.dtype == np.float32 and Tf.dtype == np.float32
+        assert (np.array_equal(R[:, 0, 0], R[:, 1, 1]) and np.array_equal(R[:, 0, 1], -R[:, 1, 0]) and np.all(R[:, 2, 2] == 1)
+                and not R[:, :2, 2].any() and not R[:, 2, :2].any())
+        # the capture's own summary of this IPO run must be what the cache holds
+        assert np.array_equal(np.arctan2(R[:, 1, 0], R[:, 0, 0]).astype(np.float32), full["ipo_angle"][sid])
+        cs.append(np.stack([R[:, 0, 0], R[:, 1, 0]], -1))
+        Ts.append(Tf[:, 0, :])
+    save(tag + "_ipo", cs=np.stack(cs).astype(np.float32), T=np.stack(Ts).astype(np.float32), inputs_sha=full["inputs_sha"])
+
+
+def gen_driver_ipo_pins():
+    _driver_ipo_pin("driver_h36m_full", 886, 1, 101, 17, [0, 1, 4], 3.0, 0.5, "uniform", "h36m", CACHE)
+    _driver_ipo_pin("driver_pw3d_full", 1015, 50, 103, 19, list(range(17)), 8.0, 0.2, "uniform", "3dpw", CACHE)
+    _driver_ipo_pin("driver_pw3d_full_b", 1015, 50, 203, 29, list(range(17)), 8.0, 0.2, "ones", "3dpw", CACHE)
+    _driver_ipo_pin("driver_pw3d_full_c", 1015, 50, 307, 31, list(range(17)), 8.0, 0.2, "uniform", "3dpw", CACHE)
+
+
+
+def _driver_oil_f64_from_pins(tag, N, H, S, seed_pose, seed_cl, conf_mode, cache_dir):
+    """Arbiter of parity stage (A): the reference's OIL loop (opt_main.py:197-222) re-run in float64 FROM THE SAME
+    (R, T) the reference's fp32 run produced (tests/golden/<tag>_ipo.npz) - i.e. exact arithmetic on the inputs the fp32
+    reference run and the HIP loop both start from.  How far the reference's own fp32 loop drifts from it is the
+    yardstick for the HIP loop's drift.  3DPW metric (plain mean).  ~80 CPU-minutes for configs[2]; resumable."""
+    w = syn.make_weights(seed=0)
+    m = ref_model(w, torch.float64)
+    d = syn.make_poses(N, seed=seed_pose, conf_mode=conf_mode)
+    cl = syn.make_clusters(H, seed=seed_cl)
+    gt_2d, K = d["db_2d"], d["camera_param"]
+    pin = np.load(os.path.join(OUT, tag + "_ipo.npz"))
+    assert str(pin["inputs_sha"]) == _sha(gt_2d, K, cl)
+    os.makedirs(cache_dir, exist_ok=True)
+    import time
+    res_all = []
+    for sid in range(H):
+        f = os.path.join(cache_dir, f"{tag}_oil64_h{sid:02d}.npz")
+        if os.path.exists(f):
+            res = np.load(f)["res"]
+        else:
+            t0 = time.time()
+            c, s_ = pin["cs"][sid, :, 0], pin["cs"][sid, :, 1]
+            R = np.zeros((N, 3, 3), np.float32)
+            R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1], R[:, 2, 2] = c, -s_, s_, c, 1
+            noisy = (torch.ones((N, 17, 3)) * torch.tensor(cl - cl[:, 0:1, :])[sid:sid + 1])
+            x = torch.tensor(R).bmm(noisy.permute(0, 2, 1)).permute(0, 2, 1).contiguous().numpy()     # fp32, opt_main.py:201
+            res, _, _ = run_ref_oil(m, x, gt_2d[:, :, :2], gt_2d[:, :, 2].copy(), K, pin["T"][sid][:, None, :], S, [],
+                                    torch.float64)
+            np.savez(f, res=res)
+            print(f"  {tag} oil64: hypothesis {sid + 1}/{H} in {time.time() - t0:.0f} s", flush=True)
+        res_all.append(res)
+    br = np.swapaxes(np.array(res_all), 0, 1)
+    gtc = (d["db_3d"] - d["db_3d"][:, 0:1]).astype(np.float64)
+    e1 = np.linalg.norm(br - gtc[:, None], axis=-1).mean(-1)
+    e2 = np.zeros((N, H))
+    for n in range(N):
+        for h in range(H):
+            Z = procrustes(gtc[n].copy(), br[n, h].copy())[1]
+            e2[n, h] = np.mean(np.sqrt(np.square(Z - gtc[n]).sum(axis=1)))
+    save(tag + "_oil64", N=np.int64(N), H=np.int64(H), S=np.int64(S), err_p1=e1.astype(np.float32), err_p2=e2.astype(np.float32),
+         best_p1=e1.min(1), best_p2=e2.min(1), argmin_p1=e1.argmin(1).astype(np.int32), argmin_p2=e2.argmin(1).astype(np.int32),
+         mpjpe=np.float64(e1.min(1).mean()), pa_mpjpe=np.float64(e2.min(1).mean()), inputs_sha=pin["inputs_sha"])
+
+
+def gen_driver_pw3d_full_oil64():
+    _driver_oil_f64_from_pins("driver_pw3d_full", 1015, 50, 1000, 103, 19, "uniform", CACHE)
+
+
 
 GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo, oil=gen_oil,
             eval=gen_eval, driver=gen_driver, datasets=gen_datasets,
             driver_files=gen_driver_files, samplers=gen_samplers, pc_generic=gen_pc_generic, hp3d_ski=gen_3dhp_ski, driver_full=gen_driver_full,
             driver_h36m_full=gen_driver_h36m_full, driver_pw3d_full=gen_driver_pw3d_full,
             driver_h36m_full_f64=gen_driver_h36m_full_f64, driver_pw3d_full_f64=gen_driver_pw3d_full_f64,
-            driver_pw3d_full_b=gen_driver_pw3d_full_b, driver_pw3d_full_c=gen_driver_pw3d_full_c)
-SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64", "driver_pw3d_full_b", "driver_pw3d_full_c"}     # only with --only
+            driver_pw3d_full_b=gen_driver_pw3d_full_b, driver_pw3d_full_c=gen_driver_pw3d_full_c,
+            driver_ipo_pins=gen_driver_ipo_pins, driver_pw3d_full_oil64=gen_driver_pw3d_full_oil64)
+SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64", "driver_pw3d_full_b", "driver_pw3d_full_c", "driver_ipo_pins", "driver_pw3d_full_oil64"}     # only with --only
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
