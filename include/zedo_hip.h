@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ZEDO_ABI_VERSION 2
+#define ZEDO_ABI_VERSION 3   /* 3: + zedo_reproj_degenerate, zedo_pose_min, zedo_weights_set_math / zedo_weights_get_math */
 
 #define ZEDO_OK 0
 #define ZEDO_E_BADARG (-1)      /* NULL pointer, non-positive size, unsupported dimension */
@@ -99,6 +99,14 @@ size_t zedo_workspace_bytes(int B);
  */
 int zedo_reproj_prepare(const float *d_uv, const float *d_K, const float *d_conf, int N, int J,
                         float *d_geom, float *d_conf_clamped, void *stream);
+
+/* How many of the N poses have a SINGULAR least-squares system for T (simple_zeroshot_opt.py:73-92): with the centred
+ * closed form the 3x3 normal matrix is singular exactly when sum_j W_j |r_j - rbar|^2 == 0 - every ray of the pose
+ * coincides.  The reference's torch.inverse(AtA) raises there (:89-92); the solve kernels would divide by zero
+ * and produce a NaN T.  The quantity depends only on d_geom (not on x or the step), so it is checked ONCE per
+ * problem: the host mirror raises like the reference does when a solve is requested and *h_count > 0.
+ * Same fp32 arithmetic as the kernels' denominator.  Synchronises `stream`. */
+int zedo_reproj_degenerate(const float *d_geom, int N, int J, int *h_count, void *stream);
 
 /* gradient_field_gen (simple_zeroshot_opt.py:46-125, noise_type None):
  *   solve_T != 0 : T = weighted least-squares translation (:73-93, sign fix :93), written to d_T
@@ -166,6 +174,12 @@ int zedo_rotate_init(const float *d_x0, const float *d_R, float *d_x, int B, int
  */
 int zedo_min_mpjpe(const float *d_pred, const double *d_gt, int B, int N, int J, long long row_offset,
                    int procrustes, double *d_err, double *d_best, int *d_best_h, void *stream);
+
+/* The second half of zedo_min_mpjpe on its own: per pose n the minimum of d_err over the hypotheses present in
+ * [0,B) and the first hypothesis index that attains it (np.amin / np.argmin, NaN wins: h36m.py:411-412).  For
+ * callers that edit the per-row errors first - eval_multi's `valid_ind` (h36m.py:396-397: hypotheses not listed for
+ * a pose are skipped) sets them to +inf - including on a row shard (row_offset). */
+int zedo_pose_min(const double *d_err, int B, int N, long long row_offset, double *d_best, int *d_best_h, void *stream);
 
 /* ---- diagnostics: sampled per-kernel timing ---------------------------------------------------------
  * Between zedo_profile_start and zedo_profile_stop every `sample_every`-th launch of each kernel class

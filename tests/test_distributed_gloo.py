@@ -70,7 +70,7 @@ def test_two_rank_min_reduction_equals_unsharded(tmp_path, protocol2):
 def _worker_gather_nan(rank, world, port, out_dir):
     sys.path.insert(0, os.path.join(ROOT, "zedo-release_amd"))
     import torch.distributed as dist
-    from zedo_hip.pipeline import gather_row_shards, reduce_min_over_ranks, shard_rows
+    from zedo_hip.pipeline import gather_row_shards, reduce_min_over_ranks, shard_hypotheses, shard_rows
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     # all-gather of uneven contiguous row shards (run.inference): 3 ranks x 5 rows cover 13 rows as 5 + 5 + 3
     total = 13
@@ -78,6 +78,13 @@ def _worker_gather_nan(rank, world, port, out_dir):
     lo, n = shard_rows(total, rank, world)
     got = gather_row_shards(full[lo:lo + n].clone(), total)
     ok_gather = bool(torch.equal(got, full))
+    # whole hypotheses per rank (the step-wise loop of non-fused configurations): H = 4 over 3 ranks = 2 + 2 + 0
+    # hypotheses of N = 3 poses, shard sizes that are NOT the shard_rows split (12 rows: 6 + 6 + 0 vs 4 + 4 + 4)
+    H4, N3 = 4, 3
+    h_lo, h_cnt = shard_hypotheses(H4, rank, world)
+    assert (h_lo, h_cnt) == [(0, 2), (2, 2), (4, 0)][rank]
+    got_h = gather_row_shards(full[h_lo * N3:(h_lo + h_cnt) * N3].clone(), H4 * N3, lo=h_lo * N3)
+    ok_gather = ok_gather and bool(torch.equal(got_h, full[:H4 * N3]))
     # more ranks than rows: the last rank holds an empty shard
     lo2, n2 = shard_rows(2, rank, world)
     got2 = gather_row_shards(full[lo2:lo2 + n2].clone(), 2)

@@ -30,7 +30,7 @@ def dev(a, dtype=torch.float32):
 
 
 def test_abi_version(zh):
-    assert zh.abi_version() == 2
+    assert zh.abi_version() == 3
 
 
 def test_schedule_tables(zh, W, weights0, golden):
@@ -218,13 +218,19 @@ def test_ipo_trajectory_golden(zh, golden, N, axes, kname):
         gp = np.maximum(np.abs(q32[it - 1] - q64[it - 1]).max(1), np.abs(s32i - s64i))
         d32 = max(np.abs(qn - q32[it - 1]).max(), np.abs(sn - s32i).max())
         rows.append(dict(it=it, hip_vs_ref64=float(dp.max()), hip_vs_ref32=float(d32), ref32_vs_ref64=float(gp.max()),
-                         hip_vs_ref64_median=float(np.median(dp)), ref32_vs_ref64_median=float(np.median(gp))))
+                         hip_vs_ref64_median=float(np.median(dp)), ref32_vs_ref64_median=float(np.median(gp)),
+                         hip_vs_ref64_p90=float(np.percentile(dp, 90)), ref32_vs_ref64_p90=float(np.percentile(gp, 90)),
+                         poses_beyond_2_gaps=int((dp > 2.0 * gp + 1e-6).sum()), poses=int(len(dp))))
     _report(f"ipo_{tag}", rows)
     for r in rows:
         if r["it"] <= 30:
             assert r["hip_vs_ref64"] <= 2.0 * r["ref32_vs_ref64"] + 1e-7, r
         else:
             assert r["hip_vs_ref64_median"] <= 2.0 * r["ref32_vs_ref64_median"] + 1e-7 and r["hip_vs_ref64"] <= 0.1, r
+            # a regression that hits a minority of the poses late in the fit must not hide behind the median: the 90th
+            # percentile is held to the same multiple of the reference's own 90th-percentile gap (+ one sign event's
+            # worth for the smallest batches, where the 90th percentile of 8 poses IS the worst pose)
+            assert r["hip_vs_ref64_p90"] <= 2.0 * r["ref32_vs_ref64_p90"] + (1e-7 if N >= 64 else 0.03), r
     assert rows[0]["hip_vs_ref64"] <= 1e-7 and rows[4]["hip_vs_ref64"] <= 2e-6, (rows[0], rows[4])
     # T0 (0 iterations): scale = 1
     R, T = zh.ipo_fit(x0, uv, K, kl, axes, ipoT, minT, 2.0, 0, norm, N)

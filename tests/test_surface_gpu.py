@@ -55,7 +55,9 @@ def test_score_fn_and_pc_sampler_surface(model, golden):
     sde = sde_lib.subVPSDE(beta_min=0.1, beta_max=20.0, N=1000, T=0.1)
     sfn = mutils.get_score_fn(sde, model, train=False, continuous=True)
     s = sfn(dev(p["x"]), torch.ones(8, device="cuda") * 0.05, None, None)
-    np.testing.assert_allclose(s.cpu().numpy(), p["score_t0p05"], atol=1e-4, rtol=1e-5)
+    # score = -eps / std: the network's round-off (eps to 3e-6, test_model_forward_surface) scaled by 1 / std(t)
+    std = float(sde.marginal_prob(torch.zeros(1, 17, 3), torch.tensor([0.05]))[1])
+    np.testing.assert_allclose(s.cpu().numpy(), p["score_t0p05"], atol=3e-6 / std, rtol=0)
     cfg = load_config(cfg_path("h36m"))
     cfg.sampling.probability_flow = True
     fn = sampling.get_sampling_fn(cfg, sde, (8, 17, 3), lambda x: x, 0.01, device=torch.device("cuda"))
@@ -95,10 +97,25 @@ def test_rotopt_fit_surface(golden):
     g = golden("ipo")
     N, kl = 8, [0, 1, 4]
     ro = RotOpt(N, axis="z", minT=0.5, maxT=2).cuda()
-    R, T = ro.fit(dev(g["cluster0"][None]), dev(g[f"db2d_{N}"][:, :, :2]), dev(g[f"K_{N}"]), kl, 3.0, iters=5)
-    q = ro.quaternion().detach().cpu().numpy()
-    np.testing.assert_allclose(q, g[f"trace_q_{N}_z_h36m"][4], atol=2e-5, rtol=0)
-    np.testing.assert_allclose(ro.scale.detach().cpu().numpy().reshape(-1), g[f"trace_scale_{N}_z_h36m"][4], atol=2e-5)
+    tag = f"{N}_z_h36m"
+    q32, s32, q64, s64 = g[f"trace_q_{tag}"], g[f"trace_scale_{tag}"], g[f"trace_q64_{tag}"], g[f"trace_scale64_{tag}"]
+    # the criterion of the C-ABI test (test_ipo_trajectory_golden) through the module surface, all 50 traced iterations:
+    # the fp64 run of the reference is the arbiter, its own fp32 run the yardstick (gap)
+    for it in range(1, q64.shape[0] + 1):
+        ro = RotOpt(N, axis="z", minT=0.5, maxT=2).cuda()
+        R, T = ro.fit(dev(g["cluster0"][None]), dev(g[f"db2d_{N}"][:, :, :2]), dev(g[f"K_{N}"]), kl, 3.0, iters=it)
+        q = ro.quaternion().detach().cpu().numpy().astype(np.float64)
+        sc = ro.scale.detach().cpu().numpy().reshape(-1).astype(np.float64)
+        dp = np.maximum(np.abs(q - q64[it - 1]).max(1), np.abs(sc - s64[it - 1].reshape(-1)))
+        gp = np.maximum(np.abs(q32[it - 1] - q64[it - 1]).max(1), np.abs(s32[it - 1].reshape(-1) - s64[it - 1].reshape(-1)))
+        if it <= 30:
+            assert dp.max() <= 2.0 * gp.max() + 1e-7, (it, dp.max(), gp.max())
+        else:
+            assert np.median(dp) <= 2.0 * np.median(gp) + 1e-7 and dp.max() <= 0.1, (it, np.median(dp), np.median(gp))
+        if it == 1:
+            assert dp.max() <= 1e-7
+        if it == 5:
+            assert dp.max() <= 2e-6
     assert R.shape == (N, 3, 3) and T.shape == (N, 1, 3)
 
 

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Sensitivity of the GPU parity suite: five one-line arithmetic mutations of the HIP path, each of which must turn
+at least one `-m gpu` test red (run on the GPU box from the repo root: `python tools/mutation_check.py [out.txt]`).
+
+Each mutant is the product library built with ONE extra -D flag (the hooks are `#ifdef ZEDO_MUT_*` lines in csrc/,
+compiled out of the product); the whole `-m gpu` suite runs against it and the failing tests are listed.  The clean
+library is rebuilt and re-tested at the end (row "none": must be all green), so no mutant is left in the tree.
+"""
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "zedo-release_amd", "csrc")
+
+MUTANTS = [
+    ("ZEDO_MUT_GN_EPS", "GroupNorm eps 1e-5 -> 2e-5 (zedo_gemm.hip epilogue; reference model.py:116)"),
+    ("ZEDO_MUT_SDE_C", "c_i * (1 + 1e-4): score coefficient of x' = a x + c eps (zedo_capi.hip schedule; sde_lib.py:187-198)"),
+    ("ZEDO_MUT_CONF2", "least-squares weight conf^4 -> conf^2 (zedo_geom.hip; simple_zeroshot_opt.py:85-88)"),
+    ("ZEDO_MUT_SWITCH", "switch to the least-squares T one iteration late (zedo_capi.hip; run/opt_main.py:203-206)"),
+    ("ZEDO_MUT_ARGMIN_TIE", "arg-min ties to the HIGHER hypothesis index (zedo_metric.hip; np.argmin, h36m.py:412)"),
+]
+
+
+def build(flag):
+    for f in os.listdir(CSRC):
+        if f.endswith(".hip"):
+            os.utime(os.path.join(CSRC, f))
+    subprocess.run(["make", "-C", CSRC, "-j4", f"EXTRA={'-D' + flag if flag else ''}"], check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+def run_suite():
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests", "-m", "gpu", "-q", "--no-header", "-rf", "-p", "no:cacheprovider"],
+                       cwd=ROOT, capture_output=True, text=True)
+    out = r.stdout + r.stderr
+    failed = sorted(set(re.findall(r"^FAILED (\S+)", out, re.M)))
+    m = re.search(r"(\d+) passed", out)
+    return failed, int(m.group(1)) if m else 0, time.time() - t0, out
+
+
+def main():
+    dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "mutation_check.txt")
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    rows, ok = [], True
+    try:
+        for flag, what in MUTANTS:
+            build(flag)
+            failed, passed, dt, out = run_suite()
+            rows.append((flag, what, failed, passed, dt))
+            ok &= len(failed) > 0
+            print(f"{flag}: {len(failed)} red / {passed} green in {dt:.0f} s", flush=True)
+    finally:
+        build(None)
+    failed, passed, dt, out = run_suite()
+    rows.append(("none", "the product library (rebuilt without any mutation)", failed, passed, dt))
+    ok &= len(failed) == 0
+    with open(dst, "w") as f:
+        f.write("mutation | what | red tests | green | suite seconds\n")
+        for flag, what, failed, passed, dt in rows:
+            f.write(f"-D{flag} | {what} | {len(failed)} | {passed} | {dt:.0f}\n")
+            for t in failed:
+                f.write(f"    RED {t}\n")
+        f.write("VERDICT: " + ("every mutation is caught and the product is green\n" if ok else
+                               "NOT every mutation is caught (or the product is red)\n"))
+    print(open(dst).read())
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -266,6 +266,9 @@ extern "C" int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, i
         const double sd = 1.0 - std::exp(2.0 * (-0.25 * t * t * (b1 - b0) - 0.5 * t * b0));
         s->a[i] = (float)(1.0 + 0.5 * beta / n_sde);
         s->c[i] = (float)(-(beta * disc) / (n_sde * sd));
+#ifdef ZEDO_MUT_SDE_C       // tools/mutation_check.py only
+        s->c[i] = (float)(-(beta * disc) / (n_sde * sd) * (1.0 + 1e-4));
+#endif
     }
     // short schedules (the per-step surface asks for one timestamp at a time) borrow the scratch owned by the
     // weights handle: no hipMalloc / hipFree of temporaries per call
@@ -331,6 +334,19 @@ extern "C" int zedo_reproj_prepare(const float *d_uv, const float *d_K, const fl
     if (!d_uv || !d_K || !d_geom || N < 1 || J < 1) return ZEDO_E_BADARG;
     HIPCHK(launch_reproj_prepare(d_uv, d_K, d_conf, N, J, d_geom, d_conf_clamped, (hipStream_t)stream));
     return ZEDO_OK;
+}
+
+extern "C" int zedo_reproj_degenerate(const float *d_geom, int N, int J, int *h_count, void *stream) {
+    if (!d_geom || !h_count || N < 1 || J < 1) return ZEDO_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    int *d_count = nullptr;
+    HIPCHK(hipMalloc(&d_count, sizeof(int)));
+    hipError_t e = hipMemsetAsync(d_count, 0, sizeof(int), st);
+    if (e == hipSuccess) e = launch_reproj_degenerate(d_geom, N, J, d_count, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_count);
+    return (int)e;
 }
 
 extern "C" int zedo_reproj_grad(const float *d_x, const float *d_geom, float *d_T, int solve_T, float *d_g, int B, int N,
@@ -429,6 +445,9 @@ extern "C" int zedo_oil_run(const zedo_weights_t *w, const zedo_schedule_t *s, f
     if (step_begin < 0 || step_end > s->S || step_begin > step_end || w->J3 != 51) return ZEDO_E_BADARG;
     if (workspace_bytes < zedo_workspace_bytes(B)) return ZEDO_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+#ifdef ZEDO_MUT_SWITCH      // tools/mutation_check.py only: the least-squares T starts one iteration late
+    switch_step += 1;
+#endif
     const size_t cap = chunk_rows_cap();
     for (size_t r0 = 0; r0 < (size_t)B; r0 += cap) {
         const int Bc = (int)std::min(cap, (size_t)B - r0), Bp = round_up(Bc, BATCH_PAD);
@@ -487,6 +506,13 @@ extern "C" int zedo_rotate_init(const float *d_x0, const float *d_R, float *d_x,
     if (!d_x0 || !d_R || !d_x || B < 1 || H < 1 || N < 1 || J < 1 || row_offset < 0) return ZEDO_E_BADARG;
     if (row_offset + (long long)B > (long long)H * N) return ZEDO_E_BADARG;
     HIPCHK(launch_rotate_init(d_x0, d_R, d_x, B, N, J, row_offset, (hipStream_t)stream));
+    return ZEDO_OK;
+}
+
+extern "C" int zedo_pose_min(const double *d_err, int B, int N, long long row_offset, double *d_best, int *d_best_h,
+                             void *stream) {
+    if (!d_err || !d_best || !d_best_h || B < 1 || N < 1 || row_offset < 0) return ZEDO_E_BADARG;
+    HIPCHK(launch_pose_min(d_err, B, N, row_offset, d_best, d_best_h, (hipStream_t)stream));
     return ZEDO_OK;
 }
 

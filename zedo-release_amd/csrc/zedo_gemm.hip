@@ -133,7 +133,12 @@ __device__ __forceinline__ void epilogue_values(const f32x16 &acc, const f32x4 (
         }
         float qs = q2.x + q2.y;
         qs += __shfl_xor(qs, 32);
-        const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(qs, 1.0f / 32.0f, 1e-5f));   // one fma, spelled out (-ffp-contract=off)
+#ifdef ZEDO_MUT_GN_EPS      // tools/mutation_check.py only: a deliberately wrong constant that the parity suite must catch
+        constexpr float GN_EPS = 2e-5f;
+#else
+        constexpr float GN_EPS = 1e-5f;
+#endif
+        const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(qs, 1.0f / 32.0f, GN_EPS));   // one fma, spelled out (-ffp-contract=off)
         const f32x2 r2 = {rstd, rstd}, c2 = {-1.44269504088896340736f, -1.44269504088896340736f}, one2 = {1.0f, 1.0f};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -700,7 +705,7 @@ static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
     // many small co-resident workgroups overlap their stores, one big tile per CU cannot.
     // (measured at 50 750 rows: 64x128 82 us; 32x128 92 us; 128x128 91 us; 64x256 108 us)
     if (a.K <= 64) {
-        // a.kpad_zero_groups: the caller vouches that k >= K - 8 is zero in X and W (pre_dense: 51 real inputs)
+        // a.kzero8: the caller vouches that k >= K - 8 is zero in X and W (pre_dense: 51 real inputs)
         if (a.K == 64 && a.kzero8) return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN, 1, 1>(a, st);
         return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);
     }

@@ -70,6 +70,9 @@ __global__ void reproj_prepare_kernel(const float *__restrict__ uv, const float 
         if (conf_out) conf_out[i] = c;
         const float w = c * c;       // rows of A and b are scaled by conf^2 (:85-88) ...
         W = w * w;                   // ... so the normal equations weight each residual by conf^4
+#ifdef ZEDO_MUT_CONF2       // tools/mutation_check.py only
+        W = w;
+#endif
     }
     float *g = geom + (size_t)i * GEOM_F;
     g[0] = (float)rx; g[1] = (float)ry; g[2] = W; g[3] = 0.0f;
@@ -81,6 +84,33 @@ hipError_t launch_reproj_prepare(const float *uv, const float *K, const float *c
     const int n = N * J;
     hipLaunchKernelGGL(reproj_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, st, uv, K, conf, N, J, geom,
                        conf_clamped);
+    return hipGetLastError();
+}
+
+// The denominator of reproj_row's T_z for every pose - it depends on the rays and weights only - with the same fp32
+// operations in the same order; poses where it is exactly zero have a singular normal matrix (zedo_reproj_degenerate).
+__global__ void reproj_degenerate_kernel(const float *__restrict__ geom, int N, int J, int *__restrict__ count) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float *gp = geom + (size_t)n * J * GEOM_F;
+    float sw = 0.f, srx = 0.f, sry = 0.f;
+    for (int j = 0; j < J; ++j) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(gp + j * GEOM_F);
+        sw += a[2]; srx += a[2] * a[0]; sry += a[2] * a[1];
+    }
+    const float iw = 1.0f / sw;
+    const float mrx = srx * iw, mry = sry * iw;
+    float den = 0.f;
+    for (int j = 0; j < J; ++j) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(gp + j * GEOM_F);
+        const float dx = a[0] - mrx, dy = a[1] - mry;
+        den += a[2] * (dx * dx + dy * dy);
+    }
+    if (den == 0.f) atomicAdd(count, 1);
+}
+
+hipError_t launch_reproj_degenerate(const float *geom, int N, int J, int *d_count, hipStream_t st) {
+    hipLaunchKernelGGL(reproj_degenerate_kernel, dim3((N + 255) / 256), dim3(256), 0, st, geom, N, J, d_count);
     return hipGetLastError();
 }
 

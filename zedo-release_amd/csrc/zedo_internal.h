@@ -115,6 +115,8 @@ hipError_t launch_ipo_fit(const float *x0, const float *uv, const float *K, cons
                           int B, int N, int J, long long row_offset, hipStream_t st);
 hipError_t launch_rotate_init(const float *x0, const float *R, float *x, int B, int N, int J, long long row_offset,
                               hipStream_t st);
+hipError_t launch_pose_min(const double *err, int B, int N, long long row_offset, double *best, int *best_h, hipStream_t st);
+hipError_t launch_reproj_degenerate(const float *geom, int N, int J, int *d_count, hipStream_t st);
 hipError_t launch_min_mpjpe(const float *pred, const double *gt, int B, int N, int J, long long row_offset,
                             int procrustes, double *err, double *best, int *best_h, hipStream_t st);
 

@@ -115,7 +115,11 @@ __device__ __forceinline__ bool min_takes(double ov, int oh, double v, int h) {
     if (h < 0) return true;
     const bool on = ov != ov, vn = v != v;
     if (on || vn) return on && (!vn || oh < h);
+#ifdef ZEDO_MUT_ARGMIN_TIE  // tools/mutation_check.py only: ties to the HIGHER hypothesis index
+    return ov < v || (ov == v && oh > h);
+#else
     return ov < v || (ov == v && oh < h);
+#endif
 }
 
 // one wavefront per pose: min / first arg-min (np.argmin tie rule) over the hypotheses held locally
@@ -144,14 +148,18 @@ __global__ void pose_min_kernel(const double *__restrict__ err, int B, int N, lo
     if (lane == 0) { best[n] = (hi >= 0) ? e : __builtin_huge_val(); best_h[n] = hi; }
 }
 
+hipError_t launch_pose_min(const double *err, int B, int N, long long row_offset, double *best, int *best_h, hipStream_t st) {
+    hipLaunchKernelGGL(pose_min_kernel, dim3((N + 3) / 4), dim3(256), 0, st, err, B, N, row_offset, best, best_h);
+    return hipGetLastError();
+}
+
 hipError_t launch_min_mpjpe(const float *pred, const double *gt, int B, int N, int J, long long row_offset,
                             int procrustes, double *err, double *best, int *best_h, hipStream_t st) {
     hipLaunchKernelGGL(row_error_kernel, dim3((B + 127) / 128), dim3(128), 0, st, pred, gt, B, N, J, row_offset,
                        procrustes, err);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(pose_min_kernel, dim3((N + 3) / 4), dim3(256), 0, st, err, B, N, row_offset, best, best_h);
-    return hipGetLastError();
+    return launch_pose_min(err, B, N, row_offset, best, best_h, st);
 }
 
 }  // namespace zedo

@@ -65,9 +65,23 @@ class ScoreModelFC_Adv(nn.Module):
         self._plist = None
         return super()._apply(fn, *a, **k)
 
+    def load_state_dict(self, *a, **k):      # assign=True replaces the parameter OBJECTS
+        self._plist = None
+        return super().load_state_dict(*a, **k)
+
+    def __setattr__(self, name, value):      # a reassigned parameter / sub-module is a new tensor object
+        if name != "_plist" and isinstance(value, (nn.Parameter, nn.Module)):
+            object.__setattr__(self, "_plist", None)
+        super().__setattr__(name, value)
+
+    def invalidate_hip_weights(self):
+        """Force a repack on the next use - for writers that bypass the version counters (`p.data.copy_`, raw pointers)."""
+        self._plist, self._packed, self._sched_cache = None, None, {}
+
     def _version(self):
         """Cheap fingerprint of the parameter values: storage address + in-place version counter of each tensor
-        (load_state_dict, optimiser steps and .copy_ bump the counter)."""
+        (load_state_dict, optimiser steps and in-place ops under no_grad bump the counter; writes through `p.data` do
+        NOT - `.data` carries a counter of its own - call invalidate_hip_weights() after those)."""
         if self._plist is None:
             self._plist = list(self.parameters())
         return tuple((p.data_ptr(), p._version) for p in self._plist)
@@ -113,5 +127,5 @@ class ScoreModelFC_Adv(nn.Module):
             else:
                 out[sel] = zedo_hip.score_eps(self.hip_weights(), sched, 0, x[sel].contiguous())
         if self.config.model.scale_by_sigma:
-            out = out / self.sigmas[t.long()].reshape(-1, 1, 1).to(out.dtype)
+            out = out / self.sigmas.to(out.device)[t.reshape(-1).long()].reshape(-1, 1, 1).to(out.dtype)   # model.py:254,294
         return out.reshape(batch.shape)

@@ -252,9 +252,17 @@ class _LoopSchedule:
 def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps=1, probability_flow=False,
                    continuous=False, denoise=True, eps=1e-3, device="cuda", oil_steps_hint=None):
     """One predictor-corrector step per call (reference :400-529)."""
+    # the closed form x' = a_i x + c_i eps(x, 999 t_i) is ONE configuration (run/_driver.py::not_fused_because lists the
+    # same fields); the two that belong to the model (continuous labels: utils.py:751-777 - for subVPSDE the reference
+    # takes the continuous branch either way; eps / sigmas[t] with scale_by_sigma: model.py:294) are checked per call
     fused = (predictor is EulerMaruyamaPredictor and corrector is NoneCorrector and probability_flow
              and isinstance(sde, sde_lib.subVPSDE))
     loop = _LoopSchedule(sde, eps, oil_steps_hint) if fused else None
+
+    def model_is_fusable(model):
+        mc = getattr(getattr(model, "config", None), "model", None)
+        return not bool(getattr(mc, "scale_by_sigma", False))
+
     pred_fn = functools.partial(shared_predictor_update_fn, sde=sde, predictor=predictor,
                                 probability_flow=probability_flow, continuous=continuous)
     corr_fn = functools.partial(shared_corrector_update_fn, sde=sde, corrector=corrector, continuous=continuous,
@@ -266,7 +274,7 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
             tval = float(t)
             if t_step is not None and t_step < 0:      # reference :499 (disabled override, kept for parity)
                 tval = 1.0
-            if fused:
+            if fused and model_is_fusable(model):
                 import zedo_hip  # noqa: F811
                 if model.training:
                     model.eval()

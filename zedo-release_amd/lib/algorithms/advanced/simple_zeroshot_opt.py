@@ -6,6 +6,8 @@
 `RotOpt.fit(...)` -> zedo_ipo_fit.  `RotOpt.forward` remains available as ordinary differentiable torch code
 for callers that use the module directly.
 """
+import threading
+
 import torch
 import torch.nn as nn
 
@@ -61,23 +63,41 @@ def perpendicular_distance(point, vector):
     return torch.sum(point * vector, dim=-1, keepdim=True) * vector - point
 
 
-_geom_cache = {}      # one entry: the step-invariant rays of the tensors the loop passes again and again
+_geom_tls = threading.local()     # per calling thread: no sharing, no locking
+_GEOM_SLOTS = 4                   # a loop alternating between a few (key2d, K, conf) triples keeps all of them
+
+
+def invalidate_ray_cache():
+    """Drop the cached rays of the calling thread.  The cache recognises a change through torch's version counters;
+    call this after writing into key2d / K / conf in a way they do not see (`t.data` writes, raw-pointer kernels)."""
+    _geom_tls.entries = []
 
 
 def _rays(uv, Kc, cc):
     """zedo_reproj_prepare for (key2d, K, conf), reused while the SAME tensor objects come back unmodified
-    (torch's version counters): the reference's loop hands gradient_field_gen identical condition / K / conf
-    tensors 1000 times per hypothesis (run/opt_main.py:203-206).  conf is clamped in place on every build, as
-    the reference does on every call (:64-66; idempotent)."""
+    (object identity + storage address + version counter + shape): the reference's loop hands gradient_field_gen
+    identical condition / K / conf tensors 1000 times per hypothesis (run/opt_main.py:203-206).  Up to _GEOM_SLOTS
+    triples per thread, least recently used out first; the cached tensors are held (so that ids stay unique) until
+    they are displaced or invalidate_ray_cache() is called.  conf is clamped in place on every build, as the reference
+    does on every call (:64-66; idempotent)."""
     import zedo_hip
-    key = tuple((id(a), a.data_ptr(), a._version, tuple(a.shape)) if a is not None else None for a in (uv, Kc, cc))
-    hit = _geom_cache.get("entry")
-    if hit is not None and hit[0] == key:
-        return hit[2]
+
+    def fingerprint():
+        return tuple((id(a), a.data_ptr(), a._version, tuple(a.shape)) if a is not None else None for a in (uv, Kc, cc))
+
+    entries = getattr(_geom_tls, "entries", None)
+    if entries is None:
+        entries = _geom_tls.entries = []
+    key = fingerprint()
+    for i, e in enumerate(entries):
+        if e[0] == key:
+            entries.append(entries.pop(i))
+            return e[2], e[3]
     geom = zedo_hip.reproj_prepare(uv, Kc, cc, cc)
-    key = tuple((id(a), a.data_ptr(), a._version, tuple(a.shape)) if a is not None else None for a in (uv, Kc, cc))
-    _geom_cache["entry"] = (key, (uv, Kc, cc), geom)          # the tensors are held so that ids stay unique
-    return geom
+    singular = zedo_hip.reproj_degenerate(geom)              # once per (key2d, K, conf): step-invariant
+    entries.append((fingerprint(), (uv, Kc, cc), geom, singular))      # fingerprint AFTER the in-place clamp of conf
+    del entries[:-_GEOM_SLOTS]
+    return geom, singular
 
 
 def gradient_field_gen(key2d, key3d, K, noise_type=None, t=None, conf=None, returnT=False, norm_true=None,
@@ -95,12 +115,14 @@ def gradient_field_gen(key2d, key3d, K, noise_type=None, t=None, conf=None, retu
     Kc = K.float().contiguous()
     if conf is not None:
         cc = conf if (conf.is_contiguous() and conf.dtype == torch.float32) else conf.float().contiguous()
-        geom = _rays(uv, Kc, cc)
+        geom, singular = _rays(uv, Kc, cc)
         if cc is not conf:
             conf.copy_(cc)
     else:
-        geom = _rays(uv, Kc, None)
+        geom, singular = _rays(uv, Kc, None)
     if t is None:
+        if singular:          # torch.inverse(AtA) of the reference raises on a singular system (:89-92)
+            raise RuntimeError(zedo_hip.SINGULAR_MSG.format(n=singular))
         T = torch.empty((B, 3), dtype=torch.float32, device=x.device)      # written by the kernel (solve_T)
         g = zedo_hip.reproj_grad(x, geom, T, True)
     else:

@@ -35,16 +35,20 @@ class ExponentialMovingAverage:
         for shadow, p in zip(self.shadow_params, _trainable(parameters)):
             shadow.sub_((1.0 - keep) * (shadow - p))
 
+    @torch.no_grad()
     def copy_to(self, parameters):
+        # p.copy_ (not p.data.copy_): `.data` has a version counter of its own, and the parameter's counter is what
+        # ScoreModelFC_Adv watches to know that its packed device copy is stale
         for shadow, p in zip(self.shadow_params, _trainable(parameters)):
-            p.data.copy_(shadow.data)
+            p.copy_(shadow.data)
 
     def store(self, parameters):
         self.collected_params = [p.clone() for p in parameters]
 
+    @torch.no_grad()
     def restore(self, parameters):
         for saved, p in zip(self.collected_params, parameters):
-            p.data.copy_(saved.data)
+            p.copy_(saved.data)
 
     def state_dict(self):
         return {k: getattr(self, k) for k in self._FIELDS}

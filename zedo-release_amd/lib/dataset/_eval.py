@@ -11,16 +11,16 @@ import torch
 
 def hypothesis_min(preds, gt_centred, protocol2, valid_ind=None, row_offset=0, device=None):
     """preds: np/torch [N,H,J,3] (reference layout) or a torch CUDA tensor of rows [B,J,3] with row = h*N + n
-    (pass it as a tuple ("rows", tensor)).  gt_centred: [N,J,3] float64 metres, root-centred.
-    Returns (best [N] float64 np, idx [N] int np)."""
+    (pass it as a tuple ("rows", tensor)); the rows may be a contiguous shard starting at global row `row_offset`.
+    gt_centred: [N,J,3] float64 metres, root-centred.  valid_ind: per pose the hypotheses that count (reference
+    h36m.py:396-397 skips the others).  Returns (best [N] float64 np, idx [N] int np)."""
     import zedo_hip
-    from zedo_hip.pipeline import dist_active, empty_selection, reduce_min_over_ranks
+    from zedo_hip.pipeline import empty_selection, reduce_min_over_ranks
     N = gt_centred.shape[0]
     if isinstance(preds, tuple) and preds[0] == "rows":
         rows = preds[1]
         device = rows.device
         if rows.shape[0] == 0:                      # empty shard (more ranks than rows)
-            assert valid_ind is None
             best, idx = reduce_min_over_ranks(*empty_selection(N, device))
             return best.cpu().numpy(), idx.cpu().numpy()
     else:
@@ -30,30 +30,44 @@ def hypothesis_min(preds, gt_centred, protocol2, valid_ind=None, row_offset=0, d
         rows = p.to(device=device, dtype=torch.float32).permute(1, 0, 2, 3).reshape(-1, p.shape[2], 3).contiguous()
     gt = torch.as_tensor(np.asarray(gt_centred, dtype=np.float64), device=device)
     err, best, idx = zedo_hip.min_mpjpe(rows, gt, N, procrustes=protocol2, row_offset=row_offset)
-    if valid_ind is not None:                       # reference: skip hypotheses not listed for a pose
-        if row_offset != 0 or rows.shape[0] % N or dist_active():
-            raise NotImplementedError("valid_ind needs every hypothesis of every pose on one rank (unsharded rows)")
-        H = rows.shape[0] // N
-        e = err.reshape(H, N).T.cpu().numpy()
-        mask = np.full_like(e, np.inf)
+    if valid_ind is not None:
+        # hypotheses not listed for a pose do not take part: their error becomes +inf ON THE DEVICE, for whatever
+        # shard of the rows this rank holds, and the per-pose minimum is taken again (zedo_pose_min)
+        B = rows.shape[0]
+        H = -(-(int(row_offset) + B) // N)
+        ok = np.zeros((H, N), dtype=bool)
         for n in range(N):
-            mask[n, list(valid_ind[n])] = 0
-        e = e + mask
-        return e.min(1), e.argmin(1)
+            v = [int(h) for h in valid_ind[n] if 0 <= int(h) < H]
+            ok[v, n] = True
+        ok_rows = torch.as_tensor(ok.reshape(-1)[int(row_offset):int(row_offset) + B], device=device)
+        err = torch.where(ok_rows, err, torch.full_like(err, float("inf")))
+        best, idx = zedo_hip.pose_min(err, N, row_offset)
+        idx = torch.where(torch.isinf(best), torch.full_like(idx, -1), idx)     # nothing listed on this rank for the pose
     best, idx = reduce_min_over_ranks(best, idx)
     return best.cpu().numpy(), idx.cpu().numpy()
 
 
-def subsample(preds, gt_centred, sample_interval):
+def subsample(preds, gt_centred, sample_interval, row_offset=0):
     """`sample_interval` of the reference's eval_multi (h36m.py:386-387, pw3d.py:297-298): every k-th prediction is
     kept and prediction i of the kept ones is scored against ground-truth item i - the reference indexes the
-    ground truth with the position in the subsampled list, not with the original index; mirrored as is."""
+    ground truth with the position in the subsampled list, not with the original index; mirrored as is.
+    -> (preds, gt, row_offset) of the subsampled problem.  Device rows ("rows", tensor [B,J,3], row = h*N + n, possibly
+    a shard starting at row_offset) are indexed on the device: the kept rows of a contiguous shard are again a
+    contiguous shard of the subsampled problem's rows h*N' + n/k, N' = ceil(N/k)."""
     if sample_interval is None:
-        return preds, gt_centred
-    if isinstance(preds, tuple):
-        raise NotImplementedError("sample_interval needs predictions in the [N,H,J,3] layout")
-    preds = preds[::sample_interval]
-    return preds, gt_centred[:len(preds)]
+        return preds, gt_centred, row_offset
+    k = int(sample_interval)
+    N = gt_centred.shape[0]
+    Nk = -(-N // k)
+    if isinstance(preds, tuple) and preds[0] == "rows":
+        rows = preds[1]
+        g = torch.arange(int(row_offset), int(row_offset) + rows.shape[0], device=rows.device)
+        keep = (g % N) % k == 0
+        lo = int(row_offset)
+        new_off = (lo // N) * Nk + -(-(lo % N) // k)       # kept rows in front of this shard
+        return ("rows", rows[keep].contiguous()), gt_centred[:Nk], new_off
+    preds = preds[::k]
+    return preds, gt_centred[:len(preds)], row_offset
 
 
 def print_table(title, cols, values, fmt="%.5f"):

@@ -99,7 +99,7 @@ class H36MDataset3D:
         ("rows", cuda tensor [H*N,17,3]) to keep the sampler output on the device."""
         print("eval multi-hypothesis...")
         gt = self.gt_centred()
-        preds, gt = subsample(preds, gt, sample_interval)
+        preds, gt, row_offset = subsample(preds, gt, sample_interval, row_offset)
         best, idx = hypothesis_min(preds, gt, protocol2, valid_ind, row_offset)
         k = int(np.argmin(best))
         print(f"maximum MPJPE error: {min(best[k], 1000)} and it is at index: {k}, {idx[k]}")

@@ -95,7 +95,7 @@ class MPII3DHP:
         PCK / AUC need the predictions themselves: pass `preds` as [N,H,17,3] or ("rows", tensor) holding ALL rows."""
         from lib.algorithms.advanced.utils import compute_AUC, compute_PCK
         print("eval multi-hypothesis...")
-        preds, gt = subsample(preds, self.gt_centred(), sample_interval)
+        preds, gt, row_offset = subsample(preds, self.gt_centred(), sample_interval, row_offset)
         best, idx = hypothesis_min(preds, gt, protocol2, valid_ind, row_offset)
         N = len(best)
         if isinstance(preds, tuple):

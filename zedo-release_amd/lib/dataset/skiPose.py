@@ -67,7 +67,7 @@ class skiPose:
     def eval_multi(self, preds, protocol2=False, print_verbose=False, sample_interval=None, valid_ind=None, row_offset=0):
         """Best-of-H mean (PA-)MPJPE over poses (reference :159-205)."""
         print("eval multi-hypothesis...")
-        preds, gt = subsample(preds, self.gt_centred(), sample_interval)
+        preds, gt, row_offset = subsample(preds, self.gt_centred(), sample_interval, row_offset)
         best, idx = hypothesis_min(preds, gt, protocol2, valid_ind, row_offset)
         error = float(np.mean(best))
         print(f"mean PA-MPJPE : {error}" if protocol2 else f"mean MPJPE : {error}")

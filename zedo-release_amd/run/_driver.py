@@ -120,10 +120,11 @@ def not_fused_because(config):
     return None
 
 
-def stepwise_loop(config, model, sde, sample_poses, gt_2d, K, S, device):
+def stepwise_loop(config, model, sde, sample_poses, gt_2d, K, S, device, hypotheses=None):
     """run/opt_main.py:166-222 as written there - one hypothesis at a time, IPO through RotOpt (one zedo_ipo_fit
     launch), then S iterations of gradient_field_gen + sampling_fn with the host round trip the reference's
-    pc_sampler makes - for configurations outside the fused pipeline.  Returns rows [H*N,17,3] (h-major)."""
+    pc_sampler makes - for configurations outside the fused pipeline.  hypotheses = (first, count): only that
+    contiguous range of the hypothesis loop (one rank's share).  Returns rows [count*N,17,3] (h-major)."""
     from lib.algorithms.advanced import sampling
     from lib.algorithms.advanced.simple_zeroshot_opt import RotOpt, gradient_field_gen
     z = config.ZeDO
@@ -136,7 +137,8 @@ def stepwise_loop(config, model, sde, sample_poses, gt_2d, K, S, device):
     centred = torch.tensor(sample_poses - sample_poses[:, 0:1, :], device=device).float()
     timestamp = torch.linspace(sde.T, z.sampling_eps, S, device=device)
     out = []
-    for sid in range(len(sample_poses)):
+    h_lo, h_cnt = (0, len(sample_poses)) if hypotheses is None else hypotheses
+    for sid in range(h_lo, h_lo + h_cnt):
         x0 = centred[sid:sid + 1]
         rot_opt = RotOpt(N, axis=z.RotAxes, minT=z.IPO_minScaleT, maxT=z.IPO_maxScaleT).to(device)
         R, T = rot_opt.fit(x0, condition, Kd, z.IPO_keylist, z.IPO_T, z.IPO_iterations)
@@ -153,6 +155,8 @@ def stepwise_loop(config, model, sde, sample_poses, gt_2d, K, S, device):
                                          t=timestamp[i], t_step=i, args=None)
                 denoise_x = torch.as_tensor(results).to(device)
         out.append(denoise_x)
+    if not out:
+        return torch.empty((0, N_JOINTS, JOINT_DIM), dtype=torch.float32, device=device)
     return torch.cat(out, 0).contiguous()
 
 
@@ -160,7 +164,7 @@ def run(args, inference=False):
     from lib.algorithms.advanced import sde_lib
     from lib.algorithms.advanced.model import ScoreModelFC_Adv
     from lib.algorithms.ema import ExponentialMovingAverage
-    from zedo_hip.pipeline import Pipeline, ZeDOConfig, force_dist, gather_row_shards, shard_rows
+    from zedo_hip.pipeline import Pipeline, ZeDOConfig, force_dist, gather_row_shards, shard_hypotheses, shard_rows
 
     config = load_config(args.config)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -216,15 +220,18 @@ def run(args, inference=False):
         pipe = Pipeline(model.hip_weights(), cfg, device).load(sample_poses, gt_2d, K)
         x, T = pipe.run(row_offset=lo, rows=rows)
     else:
-        if use_dist and world > 1:
-            raise NotImplementedError(f"multi-GPU runs use the fused pipeline, which this configuration leaves ({why})")
-        print(f"configuration outside the fused pipeline ({why}): stepping the loop of run/opt_main.py:166-222 "
-              "through the per-step sampling_fn surface")
-        x = stepwise_loop(config, model, sde, sample_poses, gt_2d, K, S, device)
+        # the per-step surface runs one hypothesis of ALL poses at a time (a batch of N rows with the global loss
+        # normaliser of IPO), so ranks share the hypothesis loop: whole hypotheses, contiguous, unpadded
+        h_lo, h_cnt = shard_hypotheses(H, rank, world)
+        lo, rows = h_lo * N, h_cnt * N
+        if rank == 0:
+            print(f"configuration outside the fused pipeline ({why}): stepping the loop of run/opt_main.py:166-222 "
+                  f"through the per-step sampling_fn surface, hypotheses split over {world} rank(s)")
+        x = stepwise_loop(config, model, sde, sample_poses, gt_2d, K, S, device, hypotheses=(h_lo, h_cnt))
 
     batch_results = None
     if inference:          # results.npy holds every hypothesis: [N, H, 17, 3] (run/inference.py:233-236)
-        full = gather_row_shards(x, H * N)            # one RCCL all-gather of the row shards
+        full = gather_row_shards(x, H * N, lo=None if why is None else lo)     # one RCCL all-gather of the row shards
         batch_results = full.reshape(H, N, N_JOINTS, JOINT_DIM).permute(1, 0, 2, 3).cpu().numpy()
         if rank == 0:
             np.save(args.out, batch_results)

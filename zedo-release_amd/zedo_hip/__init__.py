@@ -41,6 +41,7 @@ SIGNATURES = {
     "zedo_schedule_read": (_i, [_vp, _vp, _vp, _vp]),
     "zedo_workspace_bytes": (_sz, [_i]),
     "zedo_reproj_prepare": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "zedo_reproj_degenerate": (_i, [_vp, _i, _i, _vp, _vp]),
     "zedo_reproj_grad": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _ll, _vp]),
     "zedo_score_eps": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "zedo_sde_step": (_i, [_vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
@@ -50,6 +51,7 @@ SIGNATURES = {
                                  _i, _ll, _vp]),
     "zedo_rotate_init": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _vp]),
     "zedo_min_mpjpe": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp]),
+    "zedo_pose_min": (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp]),
     "zedo_probe_mfma_peak": (_i, [_i, _vp, _vp, _vp]),
     "zedo_profile_start": (_i, [_i, _i]),
     "zedo_profile_stop": (_i, [_vp, _vp, _vp]),
@@ -195,6 +197,18 @@ def reproj_prepare(uv, K, conf=None, conf_clamped_out=None):
     return geom
 
 
+def reproj_degenerate(geom):
+    """Number of poses whose least-squares system for T is singular (zedo_reproj_degenerate; synchronises)."""
+    _need_gpu()
+    n = ctypes.c_int(0)
+    _check(_lib.zedo_reproj_degenerate(_p(geom), geom.shape[0], geom.shape[1], ctypes.cast(ctypes.byref(n), _vp), _stream()))
+    return int(n.value)
+
+
+SINGULAR_MSG = ("gradient_field_gen: the least-squares system for T is singular for {n} pose(s) - every camera ray of the "
+                "pose coincides; the reference's torch.inverse(AtA) raises here (simple_zeroshot_opt.py:89-92)")
+
+
 def reproj_grad(x, geom, T, solve_T, row_offset=0):
     """gradient_field_gen body: returns g [B,J,3]; T [B,3] is overwritten when solve_T."""
     _need_gpu()
@@ -281,6 +295,16 @@ def min_mpjpe(pred, gt_centred, N, procrustes=False, row_offset=0):
     _check(_lib.zedo_min_mpjpe(_p(pred), _p(gt_centred, torch.float64), B, N, J, int(row_offset), int(bool(procrustes)),
                                _p(err, torch.float64), _p(best, torch.float64), _p(best_h, torch.int32), _stream()))
     return err, best, best_h
+
+
+def pose_min(err, N, row_offset=0):
+    """Per-pose minimum / first arg-min over the hypotheses of the (possibly edited) per-row errors (zedo_pose_min)."""
+    _need_gpu()
+    best = torch.empty((N,), dtype=torch.float64, device=err.device)
+    best_h = torch.empty((N,), dtype=torch.int32, device=err.device)
+    _check(_lib.zedo_pose_min(_p(err, torch.float64), err.shape[0], N, int(row_offset), _p(best, torch.float64),
+                              _p(best_h, torch.int32), _stream()))
+    return best, best_h
 
 
 def probe_mfma_peak(iters=100000):

@@ -15,7 +15,8 @@ import os
 import numpy as np
 import torch
 
-from . import (Schedule, Weights, ipo_fit, min_mpjpe, oil_run, reproj_prepare, rotate_init)
+from . import (SINGULAR_MSG, Schedule, Weights, ZedoError, ipo_fit, min_mpjpe, oil_run, reproj_degenerate, reproj_prepare,
+               rotate_init)
 
 
 def linspace_f32(start, end, steps):
@@ -71,6 +72,7 @@ class Pipeline:
         with torch.cuda.device(self.device):
             # the reference clamps conf in place inside gradient_field_gen; keep that observable
             self.geom = reproj_prepare(self.uv, self.K, self.conf, self.conf)
+            self.singular_poses = reproj_degenerate(self.geom)     # once per problem (the rays do not change)
         return self
 
     def run(self, row_offset=0, rows=None, oil_steps=None):
@@ -85,6 +87,8 @@ class Pipeline:
             return (torch.empty((0, self.x0.shape[1], 3), dtype=torch.float32, device=self.device),
                     torch.empty((0, 3), dtype=torch.float32, device=self.device))
         with torch.cuda.device(self.device):
+            if S > c.OIL_iterations // 5 and self.singular_poses:     # the loop reaches the least-squares T
+                raise ZedoError(SINGULAR_MSG.format(n=self.singular_poses))
             R, T = ipo_fit(self.x0, self.uv, self.K, c.IPO_keylist, c.RotAxes, c.IPO_T, c.IPO_minScaleT,
                            c.IPO_maxScaleT, c.IPO_iterations, self.N * len(c.IPO_keylist) * 2, B, row_offset)
             x = rotate_init(self.x0, R, self.N, row_offset)
@@ -138,21 +142,50 @@ def reduce_min_over_ranks(best, idx):
     return g, cand.to(torch.int32)
 
 
-def gather_row_shards(x_local, total_rows):
-    """All ranks' contiguous row shards (the split of shard_rows) -> the full [total_rows, ...] tensor on every
-    rank: one all-gather of equally sized (last one padded) shards.  run.inference writes every hypothesis of
-    every pose (run/inference.py:233-236), so its result cannot stay sharded."""
+def gather_row_shards(x_local, total_rows, lo=None):
+    """All ranks' contiguous row shards -> the full [total_rows, ...] tensor on every rank: one all-gather of equally
+    sized (padded) shards.  run.inference writes every hypothesis of every pose (run/inference.py:233-236), so its
+    result cannot stay sharded.  lo = None: the shards are the split of shard_rows(total_rows, rank, world); lo = this
+    rank's first global row: any contiguous, ordered, gap-free split (e.g. whole hypotheses per rank,
+    shard_hypotheses) - the shard sizes then travel in one small all-gather first."""
     import torch.distributed as dist
     if not dist_active():
         assert x_local.shape[0] == total_rows
         return x_local
     world = dist.get_world_size()
-    per = -(-total_rows // world)
-    pad = torch.zeros((per,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
+    tail = tuple(x_local.shape[1:])
+    if lo is None:
+        per = -(-total_rows // world)
+        counts = None
+    else:
+        mine = torch.tensor([int(lo), x_local.shape[0]], dtype=torch.int64, device=x_local.device)
+        allc = torch.empty((world * 2,), dtype=torch.int64, device=x_local.device)
+        dist.all_gather_into_tensor(allc, mine)
+        counts = allc.reshape(world, 2).cpu().tolist()
+        per = max(1, max(c for _, c in counts))
+    pad = torch.zeros((per,) + tail, dtype=x_local.dtype, device=x_local.device)
     pad[:x_local.shape[0]] = x_local
-    out = torch.empty((world * per,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
+    out = torch.empty((world * per,) + tail, dtype=x_local.dtype, device=x_local.device)
     dist.all_gather_into_tensor(out, pad)
-    return out[:total_rows]
+    if counts is None:
+        return out[:total_rows]
+    full = torch.empty((total_rows,) + tail, dtype=x_local.dtype, device=x_local.device)
+    covered = 0
+    for r, (rlo, cnt) in enumerate(counts):
+        if cnt:
+            assert rlo == covered, "row shards must be contiguous, ordered and gap-free"
+            full[rlo:rlo + cnt] = out[r * per:r * per + cnt]
+            covered += cnt
+    assert covered == total_rows
+    return full
+
+
+def shard_hypotheses(H, rank, world):
+    """Contiguous, unpadded split of the H hypotheses (EvaSampler.py:78-107 applied to hypotheses): for loops that
+    cannot split inside a hypothesis (the step-wise sampler surface runs one hypothesis of all N poses at a time)."""
+    per = -(-H // world)
+    lo = min(rank * per, H)
+    return lo, min(lo + per, H) - lo
 
 
 def shard_rows(total_rows, rank, world):
