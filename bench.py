@@ -137,6 +137,26 @@ def cpu_baseline(weights, cfg_kw, seed):
                        f"extrapolated to H={N_HYPO}, S={S_OIL}")
 
 
+def roofline_f16x3(h2, rows_launch):
+    """Roofline object of the split-fp16 hidden layer: three fp16 MFMAs (al.bh + ah.bl + ah.bh) per fp32 product block:
+    ISSUED flop against the dense fp16 peak, plus the bytes the tiles pull through LDS-DMA against what that path
+    sustains (the binding resource)."""
+    issued = 3 * 2.0 * rows_launch * 1024 * 1024
+    ghz = h2.get("shader_clock_ghz") or 0.0
+    dma_bytes = (rows_launch / 128.0) * 8 * 64 * (128 + 128) * 64      # row tiles x column tiles x k blocks x 16 KB
+    t = h2["avg_ms"] * 1e-3
+    return dict(bound="mfma", kernel="zedo::layer16_pair_kernel (128x128 tiles, split-fp16 operands, 3 x v_mfma_f32_32x32x16_f16 per 16-k block)",
+                achieved=round(issued / t / 1e12, 1), peak=2500.0, unit="TFLOP/s", frac=round(issued / t / 1e12 / 2500.0, 4),
+                traffic=None, fp32_equivalent_tflops=round(2.0 * rows_launch * 1024 * 1024 / t / 1e12, 1),
+                avg_launch_ms=round(h2["avg_ms"], 4), sampled_launches=h2["samples"], launches=h2["launches"],
+                kernel_shader_clock_ghz=round(ghz, 3) if ghz else None,
+                frac_at_kernel_clock=(round(issued / t / 1e12 / (2500.0 * ghz / 2.4), 4) if ghz else None),
+                lds_dma_bytes_per_launch=int(dma_bytes), lds_dma_tb_per_s=round(dma_bytes / t / 1e12, 2),
+                lds_dma_sustained_tb_per_s=(round(16.0 * 256 * ghz * 1e9 / 1e12, 2) if ghz else None),
+                note="power management holds the shader clock near 1.8 GHz under the dense fp16 MFMA stream; operands cross "
+                     "L2 -> LDS at 4 B per element and LDS-DMA sustains ~16 B/clk/CU (tools/ubench/ubench_f16x3.hip)")
+
+
 def selection_digest(out):
     """sha256 over the per-pose best errors and winning hypothesis indices of both protocols (bit-exact
     comparison of two runs, e.g. with and without the RCCL exchange step)."""
@@ -231,6 +251,9 @@ def main():
     ap.add_argument("--hypo", type=int, default=N_HYPO)
     ap.add_argument("--oil", type=int, default=S_OIL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--math", choices=("f32", "f16x3"), default="f32",
+                    help="arithmetic of the hidden layers for the HEADLINE numbers (default: exact fp32 MFMA)")
+    ap.add_argument("--no-alt-mode", action="store_true", help="skip the second timed run in the other math mode (alt_mode object)")
     ap.add_argument("--dry-launch", action="store_true", help="print the rank environments the launcher would start, and exit")
     a = ap.parse_args()
     if a.gpus < 1:
@@ -272,6 +295,7 @@ def main():
     d = syn.make_poses(N_total, seed=2024, dtype3d=np.float64 if (h36m and wl["select"] == "h36m") else np.float32)
     clusters = syn.make_clusters(H, seed=2024)
     cfg = (ZeDOConfig.h36m if h36m else ZeDOConfig.pw3d)(OIL_iterations=S)
+    os.environ["ZEDO_MATH"] = a.math
     pipe = Pipeline(weights, cfg, dev).load(clusters, d["db_2d"], d["camera_param"])
     if wl["select"] == "h36m":          # millimetre float64 ground truth, centred the way h36m.py:400-401 does
         mm = d["db_3d"] * 1000.0
@@ -302,20 +326,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        one_pass()
-    fence()
-    zh.profile_start(sample_every=37, max_samples=4096)   # prime stride: samples all four hidden layers evenly
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        x, out = one_pass()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = zh.profile_stop()
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed_run():
+        for _ in range(a.warmup):
+            one_pass()
+        fence()
+        zh.profile_start(sample_every=37, max_samples=4096)   # prime stride: samples all four hidden layers evenly
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            x, out = one_pass()
+        fence()
+        dt = time.perf_counter() - t0
+        prof = zh.profile_stop()
+        if use_dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, prof, x, out
+
+    dt, prof, x, out = timed_run()
+    # the other arithmetic mode of the hidden layers on the same problem (reported as alt_mode, never as `value`)
+    alt = None
+    if not a.no_alt_mode and wl["select"] != "gather":
+        alt_math = "f16x3" if a.math == "f32" else "f32"
+        pipe.weights.set_math(alt_math)
+        dt2, prof2, _, out2 = timed_run()
+        pipe.weights.set_math(a.math)
+        alt = dict(math=alt_math, dt=dt2, prof=prof2, out=out2)
 
     box_tf = box_ghz = None
     if rank == 0:
@@ -341,7 +377,10 @@ def main():
                 traffic = tj.get("hidden_dense_bytes_per_launch")
                 mfma_busy = {k: round(v["mfma_util"], 4) for k, v in tj.get("kernels", {}).items()
                              if k.startswith("layer_pair_kernel") and "mfma_util" in v} or None
-            roof = dict(bound="mfma", kernel="zedo::layer_pair_kernel<{GN_SILU|GN_SILU_RES}> (128x128 tiles on 16-deep K tiles, 3 workgroups per CU, + 32x128 / 64x128 remainder tiles in the same launch): "
+            if a.math == "f16x3":
+                roof = roofline_f16x3(hid, rows_launch)
+            else:
+              roof = dict(bound="mfma", kernel="zedo::layer_pair_kernel<{GN_SILU|GN_SILU_RES}> (128x128 tiles on 16-deep K tiles, 3 workgroups per CU, + 32x128 / 64x128 remainder tiles in the same launch): "
                                              "one 1024x1024 dense layer + GroupNorm + SiLU [+ residual] over all rows",
                         achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
@@ -381,7 +420,9 @@ def main():
             "metric": "poses/sec (1000-step sampler, H=50)", "value": round(poses_per_s, 3), "unit": "poses/s",
             "n_gpus": world, "rccl_ranks": (dist.get_world_size() if use_dist else 1),
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            # exact fp32 throughout by default; --math f16x3: fp32 state / epilogues / thin layers, hidden layers as split-fp16 products
+            "dtype": "f32" if a.math == "f32" else "f32 (hidden layers: split fp16 x3, fp32 accumulate)", "math": a.math, "data": "synthetic",
             "config": {"workload": (wl["name"] if stated else wl["name"] + " - NON-STATED size") +
                                    f": N={per} poses{'/GPU' if scaling == 'weak' else ' in total'} x H={H} hypotheses, "
                                    f"IPO 500 it ({len(cfg.IPO_keylist)} joints) + {S} OIL steps + {what}; "
@@ -392,11 +433,34 @@ def main():
             "end_to_end_tflops": round(row_steps_per_s * FLOP_PER_ROW_STEP / 1e12, 2),
             # all six layers' algorithmic FLOP over the wall time of the whole pass (IPO, reprojection, selection,
             # launch gaps included) against the same fp32-MFMA peak
-            "end_to_end_frac": round(row_steps_per_s * FLOP_PER_ROW_STEP / 1e12 / PEAK_FP32_MFMA_TFLOPS / world, 4),
+            "end_to_end_frac": (round(row_steps_per_s * FLOP_PER_ROW_STEP / 1e12 / PEAK_FP32_MFMA_TFLOPS / world, 4)
+                                if a.math == "f32" else None),     # algorithmic fp32 flop against the fp32 peak: exact-fp32 mode only
             **quality,
             "roofline": roof,
             "kernel_time_ms_sampled_avg": {k: (round(v["avg_ms"], 4) if v["avg_ms"] else None) for k, v in prof.items()},
         }
+        if alt is not None:
+            h2 = alt["prof"]["hidden_dense"]
+            pps2 = N_total * a.steps / alt["dt"]
+            cap = int(os.environ.get("ZEDO_CHUNK_ROWS", 1 << 20))
+            rows_launch = rows / -(-rows // cap)
+            am = {"math": alt["math"], "value": round(pps2, 3), "unit": "poses/s", "ms_per_step": round(alt["dt"] / a.steps * 1e3, 2),
+                  "speedup_vs_headline": round(pps2 / poses_per_s, 3),
+                  "mpjpe_best_of_H_m": round(float(alt["out"]["p1"][0].mean().item()), 6),
+                  "pa_mpjpe_best_of_H_m": round(float(alt["out"]["p2"][0].mean().item()), 6),
+                  "d_mpjpe_vs_headline_mm": round((float(alt["out"]["p1"][0].mean().item()) - float(out["p1"][0].mean().item())) * 1e3, 4),
+                  "d_pa_mpjpe_vs_headline_mm": round((float(alt["out"]["p2"][0].mean().item()) - float(out["p2"][0].mean().item())) * 1e3, 4),
+                  "selection_sha16": selection_digest(alt["out"]),
+                  "kernel_time_ms_sampled_avg": {k: (round(v["avg_ms"], 4) if v["avg_ms"] else None) for k, v in alt["prof"].items()}}
+            if h2["avg_ms"] and alt["math"] == "f16x3":
+                am["roofline"] = roofline_f16x3(h2, rows_launch)
+            elif h2["avg_ms"]:
+                am["roofline"] = dict(bound="mfma", achieved=round(2.0 * rows_launch * 1024 * 1024 / (h2["avg_ms"] * 1e-3) / 1e12, 2),
+                                      peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", avg_launch_ms=round(h2["avg_ms"], 4),
+                                      frac=round(2.0 * rows_launch * 1024 * 1024 / (h2["avg_ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
+            line["alt_mode"] = am
+        else:
+            line["alt_mode"] = None
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights, None, 2024)
         else:

@@ -64,6 +64,23 @@ int zedo_weights_create(const float *h_params, size_t n_floats, int n_joints, in
                         int embed, int n_blocks, void *stream, zedo_weights_t **out);
 void zedo_weights_destroy(zedo_weights_t *w);
 
+/* ---- arithmetic of the four 1024x1024 hidden layers (opt-in) ---------------------------------------------------
+ * ZEDO_MATH_F32 (default): exact fp32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an fma chain per output.
+ * ZEDO_MATH_F16X3: the same layers on the fp16 matrix pipe at fp32-level accuracy: every operand travels as two fp16
+ *   pieces (a = ah + al + O(2^-24 |a|)), a 16-deep k block costs three fp16 MFMAs (al.bh + ah.bl + ah.bh, fp32
+ *   accumulation); W carries a per-layer power-of-two scale undone exactly in the epilogue; activations between the
+ *   hidden layers live in the same 4 bytes per element as two fp16 planes.  Per-product error = one fp32 rounding;
+ *   measured max |y - y_fp64| of a layer 1.4e-6 (exact-fp32 kernel: 2.3e-6).  Results differ from ZEDO_MATH_F32 in the
+ *   last bits, like any two fp32 implementations of the network do; every other kernel (pre_dense, post_dense + SDE
+ *   update, reprojection, IPO, metric) is unchanged.  Requires activations below 65504 (they are O(10): SiLU of
+ *   GroupNorm outputs).  zedo_weights_set_math builds the split copy of the hidden weights on first use and
+ *   synchronises `stream`; the mode is a property of the handle and applies to every later call that takes it.
+ */
+#define ZEDO_MATH_F32 0
+#define ZEDO_MATH_F16X3 1
+int zedo_weights_set_math(zedo_weights_t *w, int mode, void *stream);
+int zedo_weights_get_math(const zedo_weights_t *w);
+
 /* ---- per-step tables ----------------------------------------------------------------------
  * For the timestamp vector h_t[S] (torch.linspace(sde.T, eps, S), run/opt_main.py:198) builds on
  * the device, once:

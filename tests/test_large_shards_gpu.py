@@ -1,6 +1,7 @@
 """Per-GPU shards of the 8-GPU BASELINE configurations on ONE MI355X (-m gpu): configs[4] (100 000 poses x H = 50
-over 8 GPUs = 625 000 rows per GPU) and a 1 200 000-row shard that crosses the default 2^20-row chunk boundary of
-zedo_oil_run / zedo_sde_step (configs[3]'s 3.5 M-row shards are walked the same way).  Size-independent
+over 8 GPUs = 625 000 rows per GPU), a 1 200 000-row shard that crosses the default 2^20-row chunk boundary of
+zedo_oil_run / zedo_sde_step, and configs[3]'s own shard: 567 040 poses x H = 50 over 8 GPUs = 3 544 000 rows per GPU,
+walked in four chunks (three seams).  Size-independent
 properties: every row is independent of the batch it travels in, so any slice recomputed on its own (with its
 row_offset) must reproduce the full run BIT FOR BIT - at the first rows, across the chunk seam, and in the last
 chunk - through IPO, the fixed-T steps, the switch to the least-squares T, and the selection."""
@@ -19,7 +20,8 @@ def zh():
     return zedo_hip
 
 
-@pytest.mark.parametrize("N,H", [(12500, 50), (24000, 50)], ids=["625000_rows_config4_shard", "1200000_rows_two_chunks"])
+@pytest.mark.parametrize("N,H", [(12500, 50), (24000, 50), (70880, 50)],
+                         ids=["625000_rows_config4_shard", "1200000_rows_two_chunks", "3544000_rows_config3_shard_four_chunks"])
 def test_large_shard_slices_are_bitwise_the_full_run(zh, weights0, N, H):
     import zedo_oracle as O
     from lib.dataset import synthetic as syn
@@ -43,8 +45,9 @@ def test_large_shard_slices_are_bitwise_the_full_run(zh, weights0, N, H):
     assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(T).all())
     assert not torch.equal(T, T0)                        # the least-squares T replaced the IPO one
     slices = [(0, 300), (B - 333, B), (B // 2 - 77, B // 2 + 1000)]
-    if B > CHUNK:
-        slices += [(CHUNK - 300, CHUNK + 300), (CHUNK, CHUNK + 256), (CHUNK - 1, CHUNK + 1)]
+    for seam in range(CHUNK, B, CHUNK):                  # every chunk seam of the walk
+        slices += [(seam - 300, seam + 300), (seam, seam + 256), (seam - 1, seam + 1)]
+    assert len(slices) == 3 + 3 * ((B - 1) // CHUNK)
     for a, b in slices:
         Rs, Ts = zh.ipo_fit(x0, uv, K, kl, "z", 8.0, 0.2, 2.0, 500, norm, b - a, row_offset=a)
         assert torch.equal(Rs, R[a:b]) and torch.equal(Ts, T0[a:b]), ("ipo", a, b)

@@ -99,3 +99,36 @@ def test_drivers_on_rccl_are_bit_identical(tmp_path):
     for k in ("opt", "inf", "sha", "shape"):
         assert res[False][k] == res[True][k], (k, res[False][k], res[True][k])
     assert res[True]["shape"] == [30, 2, 17, 3]
+
+
+INFER_SHARD = r'''
+import hashlib, json, os, sys
+import numpy as np
+root = %r
+sys.path.insert(0, os.path.join(root, "zedo-release_amd"))
+import torch
+import run.inference as inf
+cfg = os.path.join(root, "zedo-release_amd", "configs", "optim", "concat_pose_optimization_wild.py")
+out = os.path.join(sys.argv[1], "results.npy")
+res, errs = inf.main(inf.parse_args(["prog", "--config", cfg, "--hypo", "50", "--synthetic", "12500", "--oil_iterations", "3", "--out", out]))
+r = np.load(out, mmap_mode="r")
+print("RESULT " + json.dumps(dict(shape=list(r.shape), finite=bool(np.isfinite(res).all()), errs=errs is None,
+                                  sha=hashlib.sha256(np.ascontiguousarray(r[::97]).tobytes()).hexdigest(),
+                                  group_was_used=os.environ.get("ZEDO_FORCE_DIST") == "1")))
+'''
+
+
+def test_inference_driver_at_the_config4_shard_size_through_the_all_gather(tmp_path):
+    """BASELINE configs[4] as ONE GPU of eight sees it: run.inference on 12 500 synthetic detections x H = 50 =
+    625 000 rows (run/inference.py:175-236; three OIL steps - the loop rate does not depend on S) through the
+    driver itself, with and without the process group: under ZEDO_FORCE_DIST=1 the 625 000-row result travels through
+    gather_row_shards' RCCL all-gather before results.npy is written; both runs must write the same file."""
+    res = {}
+    for dist in (False, True):
+        d = tmp_path / ("dist" if dist else "plain")
+        d.mkdir()
+        out = _run([sys.executable, "-c", INFER_SHARD % ROOT, str(d)], dist)
+        res[dist] = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res[True]["group_was_used"] and not res[False]["group_was_used"]
+    assert res[True]["shape"] == [12500, 50, 17, 3] and res[True]["finite"] and res[True]["errs"]
+    assert res[False]["sha"] == res[True]["sha"]

@@ -109,28 +109,35 @@ def test_sample_interval_on_device_rows(zh):
 
 
 def test_singular_least_squares_system_raises_like_torch_inverse(zh, weights0):
-    """All rays of a pose equal (every joint detected at the same pixel): AtA of simple_zeroshot_opt.py:89 is singular
-    and the reference's torch.inverse raises; the kernels' closed form would divide 0 by 0.  The surface and the fused
-    pipeline raise as well - but only when a least-squares T is actually requested."""
-    from lib.algorithms.advanced.simple_zeroshot_opt import gradient_field_gen
+    """An EXACTLY singular least-squares system: every joint of pose 2 detected at one pixel whose ray has exactly
+    representable coordinates (K with power-of-two focal length and centre, pixel (1024, 768): r = (0.5, 0.25)), no
+    confidences.  AtA of simple_zeroshot_opt.py:89 then has an exact zero pivot and the reference's torch.inverse raises
+    (captured: "linalg.inv: (Batch element 2): The diagonal element 3 is zero ... singular"); the kernels' closed form
+    would divide 0 by 0.  The surface and the fused pipeline raise as well - but only when a least-squares T is actually
+    requested.  (Rays that coincide only up to rounding give the reference a finite garbage T, and the kernels too.)"""
+    from lib.algorithms.advanced.simple_zeroshot_opt import gradient_field_gen, invalidate_ray_cache
     from lib.dataset import synthetic as syn
     from zedo_hip.pipeline import Pipeline, ZeDOConfig
     d = syn.make_poses(6, seed=4)
     uv = d["db_2d"][:, :, :2].copy()
-    uv[2] = uv[2, 0:1]                                     # pose 2: one pixel for all 17 joints
+    Kn = d["camera_param"].copy()
+    Kn[2] = np.array([[1024, 0, 512], [0, 1024, 512], [0, 0, 1]], np.float32)
+    uv[2] = np.array([1024.0, 768.0], np.float32)
     x = dev(0.1 * np.random.default_rng(0).standard_normal((6, 17, 3)))
-    K, T = dev(d["camera_param"]), dev(d["db_3d"][:, 0:1, :])
+    K, T = dev(Kn), dev(d["db_3d"][:, 0:1, :])
     geom = zh.reproj_prepare(dev(uv), K)
     assert zh.reproj_degenerate(geom) == 1
-    assert zh.reproj_degenerate(zh.reproj_prepare(dev(d["db_2d"][:, :, :2]), K)) == 0
-    g = gradient_field_gen(dev(uv), x, K, t=T)            # T given: no inverse in the reference either
+    assert zh.reproj_degenerate(zh.reproj_prepare(dev(d["db_2d"][:, :, :2]), dev(d["camera_param"]))) == 0
+    uv_d = dev(uv)
+    g = gradient_field_gen(uv_d, x, K, t=T)               # T given: no inverse in the reference either
     assert bool(torch.isfinite(g).all())
-    with pytest.raises(RuntimeError, match="singular"):
-        gradient_field_gen(dev(uv), x, K, t=None, returnT=True)
-    d2 = dict(d)
+    with pytest.raises(torch.linalg.LinAlgError, match="singular"):
+        gradient_field_gen(uv_d, x, K, t=None, returnT=True)
+    invalidate_ray_cache()
     db2 = d["db_2d"].copy()
     db2[:, :, :2] = uv
-    pipe = Pipeline(weights0, ZeDOConfig.h36m(OIL_iterations=10, IPO_iterations=5), "cuda").load(syn.make_clusters(2, seed=1), db2, d["camera_param"])
+    db2[:, :, 2] = 1.0
+    pipe = Pipeline(weights0, ZeDOConfig.h36m(OIL_iterations=10, IPO_iterations=5), "cuda").load(syn.make_clusters(2, seed=1), db2, Kn)
     assert pipe.singular_poses == 1
     with pytest.raises(zh.ZedoError, match="singular"):
         pipe.run()
@@ -164,7 +171,7 @@ def test_scale_by_sigma_takes_the_generic_route_and_divides_by_sigma(zh, model, 
     std = sde.marginal_prob(torch.zeros_like(x), vt)[1]
     score = -eps / std[:, None, None]
     drift, diffusion = sde.sde(x, vt)
-    drift = drift - diffusion[:, None, None] ** 2 * score * 0.5          # probability flow (sde_lib.py:93-100)
+    drift = drift - diffusion[:, None, None] ** 2 * score * 1.0          # sde_lib.py:96: the factor is 1.0 for the ODE too
     want = (x + drift * (-1.0 / sde.N)).cpu().numpy()
     np.testing.assert_allclose(xm, want, rtol=2e-6, atol=2e-7)
     # and the unscaled model on the same sampler does take the fused route, with a different result

@@ -39,8 +39,10 @@ __device__ __forceinline__ float silu_fast(float y) {
 }
 
 // BM x BN tile, WM x WN waves, NBUF-deep ring of 16-k blocks.  i = channel (W rows), j = batch row (X rows).
-template <int BM, int BN, int WM, int WN, int NBUF, int NODMA = 0>
-__global__ __launch_bounds__(WM *WN * 64) void bf_kernel(Args a) {
+// SWZ = 1: chunk (plane, k half) of tile row r is stored at k half ^ ((r >> 3) & 1): rows r and r + 8 are 768 B = 3 bank rows apart, so without it
+// every 16-lane group of a ds_read_b128 hits each 16-byte slot twice (2-way conflict, LDS reads at half rate)
+template <int BM, int BN, int WM, int WN, int NBUF, int NODMA = 0, int SWZ = 0, int WPE = 1>
+__global__ __launch_bounds__(WM *WN * 64, WPE) void bf_kernel(Args a) {
     constexpr int NW = WM * WN, TM = BM / WM, TN = BN / WN, TJ = TM / 32, TI = TN / 32;
     constexpr int RB = 96;                                   // bytes per row per k-block
     constexpr int IA = BN * 6 / 64 / NW, IB = BM * 6 / 64 / NW;   // DMA instructions per wave per k-block
@@ -63,9 +65,9 @@ __global__ __launch_bounds__(WM *WN * 64) void bf_kernel(Args a) {
     // per-lane source offsets: DMA instruction p of this wave moves 16-byte chunks g = (wid*I + p)*64 + lane of the tile
     unsigned woff[IA], xoff[IB];
 #pragma unroll
-    for (int p = 0; p < IA; ++p) { const int g = (wid * IA + p) * 64 + lane; woff[p] = (unsigned)((g / 6) * rstride + (g % 6) * 16); }
+    for (int p = 0; p < IA; ++p) { const int g = (wid * IA + p) * 64 + lane; const int r_ = g / 6, c_ = (g % 6) ^ (SWZ ? ((r_ >> 3) & 1) : 0); woff[p] = (unsigned)(r_ * rstride + c_ * 16); }
 #pragma unroll
-    for (int p = 0; p < IB; ++p) { const int g = (wid * IB + p) * 64 + lane; xoff[p] = (unsigned)((g / 6) * rstride + (g % 6) * 16); }
+    for (int p = 0; p < IB; ++p) { const int g = (wid * IB + p) * 64 + lane; const int r_ = g / 6, c_ = (g % 6) ^ (SWZ ? ((r_ >> 3) & 1) : 0); xoff[p] = (unsigned)(r_ * rstride + c_ * 16); }
     auto dma = [&](int kb, int slot) {
         const char *wk = Wbase + (size_t)kb * RB, *xk = Xbase + (size_t)kb * RB;
 #pragma unroll
@@ -85,9 +87,10 @@ __global__ __launch_bounds__(WM *WN * 64) void bf_kernel(Args a) {
     constexpr int IPW = IA + IB;
     // fragment groups of one 16-k block: G1 = {A.h, A.m, B.h, B.m} (feeds mm, hm, mh, hh), G2 = {A.l, B.l} (feeds hl, lh)
     bf16x8 a1[2][TI][2], b1[2][TJ][2], a2[TI], b2[TJ];
+    const int khs = SWZ ? (kh ^ ((li >> 3) & 1)) : kh;    // tile bases are multiples of 32 rows: (row >> 3) & 1 == (li >> 3) & 1
     auto readG1 = [&](int set, int slot) {
-        const char *As = smem + slot * SLOT + (wn * TN + li) * RB + kh * 16;
-        const char *Bs = smem + slot * SLOT + BN * RB + (wm * TM + li) * RB + kh * 16;
+        const char *As = smem + slot * SLOT + (wn * TN + li) * RB + khs * 16;
+        const char *Bs = smem + slot * SLOT + BN * RB + (wm * TM + li) * RB + khs * 16;
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -98,8 +101,8 @@ __global__ __launch_bounds__(WM *WN * 64) void bf_kernel(Args a) {
             for (int pl = 0; pl < 2; ++pl) b1[set][j][pl] = *reinterpret_cast<const bf16x8 *>(Bs + j * 32 * RB + pl * 32);
     };
     auto readG2 = [&](int slot) {
-        const char *As = smem + slot * SLOT + (wn * TN + li) * RB + kh * 16 + 64;
-        const char *Bs = smem + slot * SLOT + BN * RB + (wm * TM + li) * RB + kh * 16 + 64;
+        const char *As = smem + slot * SLOT + (wn * TN + li) * RB + khs * 16 + 64;
+        const char *Bs = smem + slot * SLOT + BN * RB + (wm * TM + li) * RB + khs * 16 + 64;
 #pragma unroll
         for (int i = 0; i < TI; ++i) a2[i] = *reinterpret_cast<const bf16x8 *>(As + i * 32 * RB);
 #pragma unroll
@@ -197,10 +200,10 @@ static void split3(const std::vector<float> &src, int rows, int K, std::vector<u
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
-template <int BM, int BN, int WM, int WN, int NBUF, int NODMA = 0>
+template <int BM, int BN, int WM, int WN, int NBUF, int NODMA = 0, int SWZ = 0, int WPE = 1>
 int run(const char *name, Args a, const std::vector<int> &rows, const std::vector<double> &cref) {
     constexpr size_t lds = (size_t)NBUF * (BM + BN) * 96;
-    auto kern = bf_kernel<BM, BN, WM, WN, NBUF, NODMA>;
+    auto kern = bf_kernel<BM, BN, WM, WN, NBUF, NODMA, SWZ, WPE>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nwg = (a.M / BM) * (a.N / BN);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -260,6 +263,12 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(dbe, hbe.data(), N * 4, hipMemcpyHostToDevice));
     a.X3 = dx; a.W3 = dw; a.bias = db; a.gamma = dg; a.beta = dbe; a.out = dy; a.M = M; a.N = N; a.K = K;
     run<128, 128, 2, 2, 2>("128x128 4 waves ring2", a, rows, cref);
+    run<128, 128, 2, 2, 2, 0, 1>("128x128 4 waves ring2 SWZ", a, rows, cref);
+    run<128, 128, 2, 2, 2, 0, 1, 3>("128x128 4 waves ring2 SWZ lb3", a, rows, cref);
+    run<128, 128, 2, 2, 2, 1, 1>("128x128 ring2 SWZ NO in-loop DMA", a, rows, cref);
+    run<256, 256, 4, 2, 2, 0, 1>("256x256 8 waves ring2 SWZ", a, rows, cref);
+    run<256, 256, 4, 2, 2, 1, 1>("256x256 ring2 SWZ NO in-loop DMA", a, rows, cref);
+    run<256, 128, 2, 2, 2, 0, 1>("256x128 4 waves ring2 SWZ", a, rows, cref);
     run<128, 128, 2, 2, 4>("128x128 4 waves ring4", a, rows, cref);
     run<256, 256, 4, 2, 2>("256x256 8 waves ring2", a, rows, cref);
     run<128, 128, 2, 2, 2, 1>("128x128 ring2 NO in-loop DMA", a, rows, cref);

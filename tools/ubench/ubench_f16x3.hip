@@ -1,0 +1,315 @@
+// Feasibility micro-benchmark: fp32-accurate dense layer on the fp16 matrix pipe ("f16x3").
+//
+// Every fp32 operand splits into two fp16 pieces a = ah + al (+ <= 2^-24 |a|: two round-to-nearest pieces of 11
+// significant bits each carry 23 bits).  The product block keeps hh, hl, lh; the dropped ll is <= 2^-24 relative:
+// the per-product error is that of ONE fp32 rounding, i.e. of a single step of the exact-fp32 fma chain, and the
+// accumulation (fp32 inside v_mfma_f32_32x32x16_f16, 64 block sums instead of 1024 chained roundings) is no worse.
+// fp16 has 5 exponent bits: W is scaled by a power of two per layer (max |w| -> ~2^14) so that its low pieces stay
+// normal; the scale is undone exactly in the epilogue.  Activations after GroupNorm + SiLU are O(1..10) and unscaled.
+// Cost: 3 fp16 MFMAs (32 cycles each) per 32x32x16 block = 96 cycles against 8 fp32 MFMAs (64 cycles) = 512: 5.3x less
+// matrix-pipe time for the SAME operand bytes (2 planes x 2 B = 4 B per element).
+//
+// Operand layout in HBM and LDS: P[row][k/16][2 planes][16] fp16 (64 contiguous bytes per row per 16-k block).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/ubench_f16x3.hip -o tools/ubench/ubench_f16x3
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct Args {
+    const uint16_t *X2;   // [M][K/16][2][16] fp16
+    const uint16_t *W2;   // [N][K/16][2][16] fp16, scaled by 2^wshift
+    const float *bias, *gamma, *beta;
+    float *out;           // [M][N] fp32
+    int M, N, K;
+    float unscale;        // 2^-wshift
+    long long *clk;       // {shader cycles, 100 MHz ticks} of workgroup 0
+};
+
+__device__ __forceinline__ void dma16(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(sbase), "v"(voff), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ float silu_fast(float y) {
+    return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.44269504088896340736f));
+}
+
+// BM x BN tile, WM x WN waves, NBUF-deep ring of KB16 16-k blocks per stage.  i = channel (W rows), j = batch row (X rows).
+template <int BM, int BN, int WM, int WN, int NBUF, int NODMA = 0, int WPE = 1, int KPS = 1>
+__global__ __launch_bounds__(WM *WN * 64, WPE) void hf_kernel(Args a) {
+    long long c0_ = 0, w0_ = 0;
+    const bool probe_ = a.clk && blockIdx.x == 0 && threadIdx.x == 0;
+    if (probe_) { c0_ = clock64(); w0_ = wall_clock64(); }
+    constexpr int NW = WM * WN, TM = BM / WM, TN = BN / WN, TJ = TM / 32, TI = TN / 32;
+    constexpr int RB = 64 * KPS;                             // bytes per row per stage (KPS 16-k blocks)
+    constexpr int CPR = RB / 16;                             // 16-byte chunks per row per stage
+    constexpr int IA = BN * CPR / 64 / NW, IB = BM * CPR / 64 / NW;   // DMA instructions per wave per stage
+    static_assert((BN * CPR) % (64 * NW) == 0 && (BM * CPR) % (64 * NW) == 0, "tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SLOT = (BN + BM) * RB;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int ncol = a.N / BN;
+    const int m0 = (lid / ncol) * BM, n0 = (lid % ncol) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN, li = lane & 31, kh = lane >> 5;
+    const size_t rstride = (size_t)(a.K / 16) * 64;          // bytes between rows in HBM
+    const char *Wbase = reinterpret_cast<const char *>(a.W2) + (size_t)n0 * rstride;
+    const char *Xbase = reinterpret_cast<const char *>(a.X2) + (size_t)m0 * rstride;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    // LDS slot (row r, chunk c) holds source chunk c ^ swz(r); swz(r) = (r >> 2) & 3 for 64-byte rows, r & 7 for 128-byte rows:
+    // every 16-lane group of a ds_read_b128 (rows li of {0-3,12-15,20-27} / {4-11,16-19,28-31}) then hits 16 distinct slots
+    auto swz = [](int row) { return CPR == 4 ? ((row >> 2) & 3) : (row & 7); };
+    unsigned woff[IA], xoff[IB];
+#pragma unroll
+    for (int p = 0; p < IA; ++p) { const int g = (wid * IA + p) * 64 + lane; const int r_ = g / CPR, c_ = (g % CPR) ^ swz(r_); woff[p] = (unsigned)(r_ * rstride + c_ * 16); }
+#pragma unroll
+    for (int p = 0; p < IB; ++p) { const int g = (wid * IB + p) * 64 + lane; const int r_ = g / CPR, c_ = (g % CPR) ^ swz(r_); xoff[p] = (unsigned)(r_ * rstride + c_ * 16); }
+    auto dma = [&](int st, int slot) {
+        const char *wk = Wbase + (size_t)st * RB, *xk = Xbase + (size_t)st * RB;
+#pragma unroll
+        for (int p = 0; p < IA; ++p) dma16(wk, woff[p], lds0 + slot * SLOT + (wid * IA + p) * 1024);
+#pragma unroll
+        for (int p = 0; p < IB; ++p) dma16(xk, xoff[p], lds0 + slot * SLOT + BN * RB + (wid * IB + p) * 1024);
+    };
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int NST = a.K / (16 * KPS);
+    constexpr int IPW = IA + IB;
+    // fragments of one 16-k block: {A.h, A.l, B.h, B.l}; two register sets (software pipeline across blocks)
+    f16x8 fa[2][TI][2], fb[2][TJ][2];
+    const int fs = swz(li);          // tile bases are multiples of 32 rows
+    auto fread = [&](int set, int slot, int kb) {      // kb = 16-k block inside the stage
+        const char *As = smem + slot * SLOT + (wn * TN + li) * RB;
+        const char *Bs = smem + slot * SLOT + BN * RB + (wm * TM + li) * RB;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fa[set][i][pl] = *reinterpret_cast<const f16x8 *>(As + i * 32 * RB + (((kb * 4 + pl * 2 + kh) ^ fs) * 16));
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fb[set][j][pl] = *reinterpret_cast<const f16x8 *>(Bs + j * 32 * RB + (((kb * 4 + pl * 2 + kh) ^ fs) * 16));
+    };
+#define FOR_TILES(stmt) _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) { stmt; }
+    auto mma = [&](int set) {       // small terms first
+        FOR_TILES(acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][1], fb[set][j][0], acc[i][j], 0, 0, 0))   // lh
+        FOR_TILES(acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][0], fb[set][j][1], acc[i][j], 0, 0, 0))   // hl
+        FOR_TILES(acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][0], fb[set][j][0], acc[i][j], 0, 0, 0))   // hh
+    };
+    // stage st in ring slot st % NBUF.  per stage: for each 16-k block: read next block's fragments, MFMAs of this block;
+    // before the last block's MFMAs: vmcnt + barrier (stage fully read by all, next stage landed), DMA of stage st+NBUF
+    static_assert(NBUF >= 2, "ring");
+#pragma unroll
+    for (int t = 0; t < NBUF; ++t) dma(min(t, NST - 1), t);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * IPW) : "memory");
+    __syncthreads();
+    fread(0, 0, 0);
+    if (NODMA & 2) fread(1, 0, 0);
+    for (int st0 = 0; st0 < NST; st0 += NBUF) {
+#pragma unroll
+        for (int slot = 0; slot < NBUF; ++slot) {
+            const int st = st0 + slot;
+            const int nxt = (slot + 1) % NBUF;
+#pragma unroll
+            for (int kb = 0; kb < KPS; ++kb) {
+                const int set = (slot * KPS + kb) & 1;
+                if (kb + 1 < KPS) {
+                    if (!(NODMA & 2)) fread(set ^ 1, slot, kb + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(set);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
+                    if (!(NODMA & 4)) __syncthreads();
+                    if (!(NODMA & 1)) dma(min(st + NBUF, NST - 1), slot);
+                    if (!(NODMA & 2)) fread(set ^ 1, nxt, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(set);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // epilogue (direct stores; only the main loop is under test here)
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int cbase = n0 + wn * TN + i * 32 + 4 * kh;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int m = m0 + wm * TM + j * 32 + li;
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaf(acc[i][j][4 * g + e], a.unscale, a.bias[cbase + 8 * g + e]);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += v[e];
+            s += __shfl_xor(s, 32);
+            const float mean = s * (1.f / 32.f);
+            float qs = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { v[e] -= mean; qs += v[e] * v[e]; }
+            qs += __shfl_xor(qs, 32);
+            const float rstd = __builtin_amdgcn_rsqf(qs * (1.f / 32.f) + 1e-5f);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = silu_fast(v[4 * g + e] * (rstd * a.gamma[cbase + 8 * g + e]) + a.beta[cbase + 8 * g + e]);
+                *reinterpret_cast<f32x4 *>(a.out + (size_t)m * a.N + cbase + 8 * g) = o;
+            }
+        }
+    }
+    if (probe_) { a.clk[0] = clock64() - c0_; a.clk[1] = wall_clock64() - w0_; }
+}
+
+static inline uint16_t f16_rn(float f) { __half h = __float2half_rn(f); uint16_t u; memcpy(&u, &h, 2); return u; }
+static inline float f16_to_f(uint16_t u) { __half h; memcpy(&h, &u, 2); return __half2float(h); }
+static void split2(const std::vector<float> &src, int rows, int K, float scale, std::vector<uint16_t> &dst, double *resid) {
+    dst.resize((size_t)rows * K * 2);
+    double worst = 0;
+    for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < K; ++k) {
+            const float a = src[(size_t)r * K + k] * scale;
+            const uint16_t h = f16_rn(a); const float r1 = a - f16_to_f(h);
+            const uint16_t l = f16_rn(r1);
+            const double rr = fabs((double)a - f16_to_f(h) - f16_to_f(l)) / (fabs((double)a) + 1e-30);
+            if (rr > worst) worst = rr;
+            uint16_t *d = &dst[((size_t)r * (K / 16) + k / 16) * 32 + (k % 16)];
+            d[0] = h; d[16] = l;
+        }
+    if (resid) *resid = worst;
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+template <int BM, int BN, int WM, int WN, int NBUF, int NODMA = 0, int WPE = 1, int KPS = 1>
+int run(const char *name, Args a, const std::vector<int> &rows, const std::vector<double> &cref) {
+    constexpr size_t lds = (size_t)NBUF * (BM + BN) * 64 * KPS;
+    auto kern = hf_kernel<BM, BN, WM, WN, NBUF, NODMA, WPE, KPS>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nwg = (a.M / BM) * (a.N / BN);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipMemset(a.out, 0xff, (size_t)a.M * a.N * 4));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(WM * WN * 64), lds, 0, a);
+    CK(hipDeviceSynchronize());
+    std::vector<float> y((size_t)a.M * a.N);
+    CK(hipMemcpy(y.data(), a.out, y.size() * 4, hipMemcpyDeviceToHost));
+    double maxd = 0, sq = 0; int nbad = 0; size_t cnt = 0;
+    for (size_t ri = 0; ri < rows.size(); ++ri) {
+        double d = 0;
+        for (int n = 0; n < a.N; ++n) { double dd = fabs((double)y[(size_t)rows[ri] * a.N + n] - cref[ri * a.N + n]); sq += dd * dd; ++cnt; if (!(dd <= d)) d = dd; }
+        if (!(d <= 1e-4)) ++nbad;
+        if (!(d <= maxd)) maxd = d;
+    }
+    for (int r = 0; r < 200; ++r) hipLaunchKernelGGL(kern, dim3(nwg), dim3(WM * WN * 64), lds, 0, a);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 100; ++r) hipLaunchKernelGGL(kern, dim3(nwg), dim3(WM * WN * 64), lds, 0, a);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 100;
+    long long ck[2] = {0, 0}; CK(hipMemcpy(ck, a.clk, 16, hipMemcpyDeviceToHost));
+    const double ghz = ck[1] > 0 ? (double)ck[0] / ((double)ck[1] / 100e6) / 1e9 : 0.0;
+    // matrix-pipe time of this launch at the clock it ran at: 3 MFMAs x 32 cycles per 32x32x16 block, 1024 SIMDs
+    const double mfma_us = 3.0 * 32.0 * ((double)a.M / 32) * (a.N / 32) * (a.K / 16) / 1024.0 / (ghz * 1e3);
+    printf("%-46s: %7.1f us  %6.1f TF(fp32-eq)  max|y-ref64| %.2e rms %.2e  bad %d  [lds %zu KB]  clock %.3f GHz  MFMA-only %.0f us (%.0f%%)\n", name, ms * 1e3,
+           2.0 * a.M * a.N * a.K / ms / 1e9, maxd, sqrt(sq / cnt), nbad, lds / 1024, ghz, mfma_us, 100.0 * mfma_us / (ms * 1e3));
+    return 0;
+}
+
+// does the matrix pipe honour fp16 denormal inputs?  one MFMA with a denormal A piece
+__global__ void denorm_probe(float *out) {
+    f16x8 av, bv;
+    for (int e = 0; e < 8; ++e) { av[e] = (_Float16)0; bv[e] = (_Float16)0; }
+    av[0] = (_Float16)3.0e-6f;      // denormal in fp16 (min normal 6.1e-5)
+    bv[0] = (_Float16)1024.0f;
+    f32x16 acc; for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+    if (threadIdx.x == 0) { out[0] = acc[0]; out[1] = (float)av[0]; }
+}
+
+int main(int argc, char **argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 49152, N = 1024, K = 1024;
+    const int mode = argc > 2 ? atoi(argv[2]) : 0;     // 1: activations like SiLU(GroupNorm) outputs incl. tiny values
+    {
+        float *d; CK(hipMalloc(&d, 16)); hipLaunchKernelGGL(denorm_probe, dim3(1), dim3(64), 0, 0, d);
+        float h[2]; CK(hipMemcpy(h, d, 8, hipMemcpyDeviceToHost));
+        printf("fp16 denormal input 3.0e-6 (stored %.6e) x 1024 through MFMA = %.6e  (%s)\n", h[1], h[0], h[0] != 0.f ? "denormals honoured" : "FLUSHED");
+    }
+    std::vector<float> hx((size_t)M * K), hw((size_t)N * K), hb(N), hg(N), hbe(N);
+    std::mt19937 rng(1); std::uniform_real_distribution<float> u(-1.f, 1.f); std::normal_distribution<float> nd(0.f, 1.f);
+    for (auto &v : hx) { if (mode == 1) { float t = 1.5f * nd(rng); v = t / (1.f + expf(-t)); } else v = u(rng); }
+    for (auto &v : hw) v = u(rng) * 0.03125f;
+    for (auto &v : hb) v = u(rng);
+    for (auto &v : hg) v = 1.0f + 0.5f * u(rng);
+    for (auto &v : hbe) v = 0.2f * u(rng);
+    float wmax = 0; for (auto v : hw) wmax = fmaxf(wmax, fabsf(v));
+    int wshift = (int)floorf(log2f(16384.0f / wmax));
+    const float wscale = ldexpf(1.f, wshift);
+    std::vector<uint16_t> x2, w2; double rx, rw;
+    split2(hx, M, K, 1.0f, x2, &rx); split2(hw, N, K, wscale, w2, &rw);
+    printf("max |w| %.4f -> scale 2^%d; worst relative split residual: x %.2e  w %.2e\n", wmax, wshift, rx, rw);
+    std::vector<int> rows; for (int r = 0; r < M; r += 997) rows.push_back(r);
+    std::vector<double> cref(rows.size() * (size_t)N);
+    for (size_t ri = 0; ri < rows.size(); ++ri) {
+        const float *xr = &hx[(size_t)rows[ri] * K];
+        std::vector<double> v(N);
+        for (int n = 0; n < N; ++n) { double s = hb[n]; const float *wr = &hw[(size_t)n * K]; for (int k = 0; k < K; ++k) s += (double)xr[k] * wr[k]; v[n] = s; }
+        for (int g = 0; g < N / 32; ++g) {
+            double mu = 0, var = 0;
+            for (int c = 0; c < 32; ++c) mu += v[g * 32 + c];
+            mu /= 32;
+            for (int c = 0; c < 32; ++c) var += (v[g * 32 + c] - mu) * (v[g * 32 + c] - mu);
+            var /= 32;
+            for (int c = 0; c < 32; ++c) { double y = (v[g * 32 + c] - mu) / sqrt(var + 1e-5) * hg[g * 32 + c] + hbe[g * 32 + c]; cref[ri * N + g * 32 + c] = y / (1 + exp(-y)); }
+        }
+    }
+    Args a{};
+    uint16_t *dx, *dw; float *db, *dg, *dbe, *dy;
+    CK(hipMalloc(&dx, x2.size() * 2)); CK(hipMalloc(&dw, w2.size() * 2)); CK(hipMalloc(&db, N * 4)); CK(hipMalloc(&dg, N * 4));
+    CK(hipMalloc(&dbe, N * 4)); CK(hipMalloc(&dy, (size_t)M * N * 4));
+    CK(hipMemcpy(dx, x2.data(), x2.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, w2.data(), w2.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dg, hg.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dbe, hbe.data(), N * 4, hipMemcpyHostToDevice));
+    long long *dclk; CK(hipMalloc(&dclk, 16)); CK(hipMemset(dclk, 0, 16)); a.clk = dclk;
+    a.X2 = dx; a.W2 = dw; a.bias = db; a.gamma = dg; a.beta = dbe; a.out = dy; a.M = M; a.N = N; a.K = K; a.unscale = 1.0f / wscale;
+    //    BM   BN  WM WN NBUF NODMA WPE KPS      NODMA bits: 1 no in-loop DMA, 2 no in-loop LDS reads, 4 no in-loop barrier
+    const int only = argc > 3 ? atoi(argv[3]) : -1;
+    int v = 0;
+#define RUN(NAME, ...) { if (only < 0 || only == v) run<__VA_ARGS__>(NAME, a, rows, cref); ++v; }
+    RUN("128x128 4w ring2 k16 lb3", 128, 128, 2, 2, 2, 0, 3, 1)
+    RUN("128x128 4w ring2 k32 lb3", 128, 128, 2, 2, 2, 0, 3, 2)
+    RUN("128x128 k16 lb3 no DMA", 128, 128, 2, 2, 2, 1, 3, 1)
+    RUN("128x128 k16 lb3 no DMA, no LDS reads", 128, 128, 2, 2, 2, 3, 3, 1)
+    RUN("128x128 k16 lb3 no DMA, no reads, no barrier", 128, 128, 2, 2, 2, 7, 3, 1)
+    RUN("128x128 k16 lb3 no DMA, no barrier (reads only)", 128, 128, 2, 2, 2, 5, 3, 1)
+    RUN("128x128 k16 lb3 no LDS reads (DMA + barrier)", 128, 128, 2, 2, 2, 2, 3, 1)
+    RUN("256x256 8w(64x128) ring2 k16 lb2", 256, 256, 4, 2, 2, 0, 2, 1)
+    RUN("256x256 8w k16 lb2 no DMA", 256, 256, 4, 2, 2, 1, 2, 1)
+    RUN("256x256 8w k16 lb2 no DMA, no LDS reads", 256, 256, 4, 2, 2, 3, 2, 1)
+    RUN("256x256 8w k16 lb2 no DMA, no reads, no barrier", 256, 256, 4, 2, 2, 7, 2, 1)
+    RUN("256x256 8w(64x128) ring4 k16", 256, 256, 4, 2, 4, 0, 1, 1)
+    RUN("256x128 8w(64x64) ring2 k32 lb2", 256, 128, 4, 2, 2, 0, 2, 2)
+    RUN("256x128 8w(64x64) ring2 k16 lb3", 256, 128, 4, 2, 2, 0, 3, 1)
+    return 0;
+}

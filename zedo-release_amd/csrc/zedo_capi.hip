@@ -30,6 +30,11 @@ struct zedo_weights {
     // one-entry schedules): posemb [ROW_PAD][E] | temb [ROW_PAD][E] | t [ROW_PAD]; guarded by scratch_mu
     float *d_scratch;
     std::mutex scratch_mu;
+    // ZEDO_MATH_F16X3 (zedo_weights_set_math): the four hidden weights as split-fp16 planes of W * 2^wshift
+    int math;
+    uint16_t *d_W16;            // [4][H][H/16][2][16]
+    float wmax_hid[4];          // max |w| per hidden layer (from the host copy at create time)
+    float unscale[4];           // 2^-wshift per hidden layer
 };
 
 struct zedo_schedule {
@@ -193,6 +198,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
 
     const float *p = h_params;
     auto next = [&](size_t n) { const float *q = p; p += n; return q; };
+    float wmax_hid_tmp[4] = {0, 0, 0, 0};
     // pre_dense
     const float *w_pre = next(H * J3), *b_pre = next(H), *w_pre_t = next(H * E), *b_pre_t = next(H);
     const float *g_pre = next(H), *be_pre = next(H);
@@ -207,6 +213,9 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     for (int l = 1; l < NLAYER; ++l) {
         const float *w = next(H * H), *b = next(H), *wt = next(H * E), *bt = next(H), *g = next(H), *be = next(H);
         memcpy(&img[o_Whid0 + (size_t)(l - 1) * H * H], w, sizeof(float) * H * H);
+        float wm = 0.f;
+        for (size_t q = 0; q < H * H; ++q) wm = std::fmax(wm, std::fabs(w[q]));
+        wmax_hid_tmp[l - 1] = wm;
         memcpy(&img[o_Wt + (size_t)l * H * E], wt, sizeof(float) * H * E);
         memcpy(&img[o_gamma + (size_t)l * H], g, sizeof(float) * H);
         memcpy(&img[o_beta + (size_t)l * H], be, sizeof(float) * H);
@@ -222,6 +231,8 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     if (!w) return (int)hipErrorOutOfMemory;
     w->J3 = J3; w->hidden = hidden; w->embed = embed; w->n_blocks = n_blocks;
     w->d_scratch = nullptr;
+    w->math = ZEDO_MATH_F32; w->d_W16 = nullptr;
+    for (int l = 0; l < 4; ++l) { w->wmax_hid[l] = wmax_hid_tmp[l]; w->unscale[l] = 1.0f; }
     hipError_t e = hipMalloc(&w->d_all, off * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&w->d_scratch, sizeof(float) * ((size_t)2 * ROW_PAD * EMB + ROW_PAD));
     if (e != hipSuccess) { (void)hipFree(w->d_all); delete w; return (int)e; }
@@ -245,7 +256,35 @@ extern "C" void zedo_weights_destroy(zedo_weights_t *w) {
     if (!w) return;
     (void)hipFree(w->d_all);
     (void)hipFree(w->d_scratch);
+    (void)hipFree(w->d_W16);
     delete w;
+}
+
+extern "C" int zedo_weights_get_math(const zedo_weights_t *w) { return w ? w->math : ZEDO_E_BADARG; }
+
+extern "C" int zedo_weights_set_math(zedo_weights_t *w, int mode, void *stream) {
+    if (!w || (mode != ZEDO_MATH_F32 && mode != ZEDO_MATH_F16X3)) return ZEDO_E_BADARG;
+    if (mode == ZEDO_MATH_F16X3 && !w->d_W16) {
+        hipStream_t st = (hipStream_t)stream;
+        for (int l = 0; l < 4; ++l)
+            if (!std::isfinite(w->wmax_hid[l])) return ZEDO_E_BADARG;          // a non-finite weight has no fp16 image
+        const size_t per = (size_t)HID * HID * 2;                                 // uint16 per layer
+        HIPCHK(hipMalloc(&w->d_W16, sizeof(uint16_t) * 4 * per));
+        hipError_t e = hipSuccess;
+        for (int l = 0; l < 4 && e == hipSuccess; ++l) {
+            // power-of-two scale that puts max |w| into [2^13, 2^14): the low pieces of all but vanishing weights stay normal
+            int ex = 0;
+            const float wm = w->wmax_hid[l];
+            if (wm > 0.f) (void)std::frexp(wm, &ex);                             // wm = f * 2^ex, f in [0.5, 1)
+            const int shift = wm > 0.f ? 14 - ex : 0;
+            w->unscale[l] = std::ldexp(1.0f, -shift);
+            e = launch_split_planes(w->W_hid[l], HID, HID, HID, std::ldexp(1.0f, shift), w->d_W16 + (size_t)l * per, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { (void)hipFree(w->d_W16); w->d_W16 = nullptr; return (int)e; }
+    }
+    w->math = mode;
+    return ZEDO_OK;
 }
 
 extern "C" int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, int S, float label_scale, float beta_min,
@@ -367,17 +406,35 @@ struct NextReproj {          // reprojection of the next loop iteration, fused i
 
 static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad, float *h, float *h1, int Bp, bool sde,
                              float sa, float sc, float *eps_out, hipStream_t st, const NextReproj &nr = NextReproj()) {
+    const bool f16 = w->math == ZEDO_MATH_F16X3;     // hidden layers on the fp16 matrix pipe; h / h1 then hold fp16 planes
     LayerArgs a{};
     a.Mp = Bp;
     // pre_dense + pre_gnorm + SiLU
     a.X = xpad; a.ldx = XLD; a.W = w->W_pre; a.ldw = XLD; a.K = XLD; a.N = HID;
     a.kzero8 = w->J3 <= XLD - 8;   // 51 real inputs: k = 56..63 are zero in xpad and in the padded weight
     a.bias = tb; a.gamma = w->gamma[0]; a.beta = w->beta[0]; a.out = h; a.ldo = HID;
+    a.out_planes = f16 ? 1 : 0;
     hipError_t e;
     { ProfScope ps(ZEDO_PROF_PRE, st); e = launch_layer(a, EPI_GN_SILU, st); }
-    a.kzero8 = 0;
+    a.kzero8 = 0; a.out_planes = 0;
     for (int blk = 0; blk < 2 && e == hipSuccess; ++blk) {
         const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
+        if (f16) {
+            // the same two layers: X, W and the activations between them as split-fp16 planes; the block's last layer adds
+            // the residual from h's planes and writes planes again (block 1) or fp32 for post_dense (block 2), in place
+            const size_t per = (size_t)HID * HID * 2;
+            Layer16Args b{};
+            b.K = HID; b.N = HID; b.Mp = Bp;
+            b.X = reinterpret_cast<const uint16_t *>(h); b.W = w->d_W16 + (size_t)(l1 - 1) * per; b.unscale = w->unscale[l1 - 1];
+            b.bias = tb + (size_t)l1 * HID; b.gamma = w->gamma[l1]; b.beta = w->beta[l1]; b.out = h1; b.out_f32 = 0; b.res = nullptr;
+            { ProfScope ps(ZEDO_PROF_HIDDEN, st); b.clk = ps.clk; e = launch_layer16(b, EPI_GN_SILU, st); b.clk = nullptr; }
+            if (e != hipSuccess) break;
+            b.X = reinterpret_cast<const uint16_t *>(h1); b.W = w->d_W16 + (size_t)(l2 - 1) * per; b.unscale = w->unscale[l2 - 1];
+            b.bias = tb + (size_t)l2 * HID; b.gamma = w->gamma[l2]; b.beta = w->beta[l2];
+            b.res = reinterpret_cast<const uint16_t *>(h); b.out = h; b.out_f32 = (blk == 1) ? 1 : 0;
+            { ProfScope ps(ZEDO_PROF_HIDDEN, st); b.clk = ps.clk; e = launch_layer16(b, EPI_GN_SILU_RES, st); b.clk = nullptr; }
+            continue;
+        }
         a.X = h; a.ldx = HID; a.W = w->W_hid[l1 - 1]; a.ldw = HID; a.K = HID; a.N = HID;
         a.bias = tb + (size_t)l1 * HID; a.gamma = w->gamma[l1]; a.beta = w->beta[l1]; a.out = h1; a.ldo = HID;
         { ProfScope ps(ZEDO_PROF_HIDDEN, st); a.clk = ps.clk; e = launch_layer(a, EPI_GN_SILU, st); a.clk = nullptr; }

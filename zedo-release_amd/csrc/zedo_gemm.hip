@@ -51,121 +51,12 @@
 //     stretches from 4.6 us (alone) to ~27 us and a CU has both workgroups inside the K loop only
 //     ~45 % of the time (tools/ubench/timeline_stats.py).
 #include "zedo_internal.h"
+#include "zedo_tile.h"
 
 #include <atomic>
 #include <cstdlib>
 
 namespace zedo {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-
-// global -> LDS DMA of 64 x 16 bytes: source = wave-uniform 64-bit base + per-lane 32-bit byte offset, destination =
-// wave-uniform LDS byte address + lane*16.  Inline asm because hipcc materialises base + zext(offset) with a 64-bit
-// VALU add per instruction inside the K loop, and VALU issue time is matrix-pipe time here.  M0 (the LDS
-// destination) is compiler-reserved: it is saved and restored inside the statement.  hipcc does not count this load
-// in its vmcnt bookkeeping - every consumer below sits behind an explicit s_waitcnt vmcnt + barrier.
-#ifdef ZEDO_EXP_XSC1   // experiment: activation (X) tiles fetched past the per-XCD L2's non-coherent lines
-#if ZEDO_EXP_XSC1 == 1
-#define ZEDO_XMOD "sc1"
-#elif ZEDO_EXP_XSC1 == 2
-#define ZEDO_XMOD "sc0 sc1"
-#else
-#define ZEDO_XMOD "nt"
-#endif
-__device__ __forceinline__ void dma16x(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 " ZEDO_XMOD "\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(sbase), "v"(voff), "s"(lds_byte_addr)
-                 : "memory");
-}
-#else
-#define dma16x dma16
-#endif
-__device__ __forceinline__ void dma16(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(sbase), "v"(voff), "s"(lds_byte_addr)
-                 : "memory");
-}
-
-__device__ __forceinline__ float silu_fast(float y) {
-    // y * sigmoid(y) with hardware exp2 / rcp (each <= 1 ulp): |rel err| <= ~3e-7
-    return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.44269504088896340736f));
-}
-
-// Per-element part of the epilogue for one 32(channel) x 32(row) accumulator tile; lane = (batch row li,
-// channel half kh), o[4g+e] belongs to channel cbase + 8g + e.  The residual / previous-x term is added by
-// the caller from the LDS stage (EPI_GN_SILU_RES: o += h;  EPI_SDE: o += sde_a * x).
-template <int EPI>
-__device__ __forceinline__ void epilogue_values(const f32x16 &acc, const f32x4 (&b4)[4], const f32x4 (&ga)[4],
-                                                const f32x4 (&be)[4], float sde_c, float (&o)[16]) {
-    if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
-        // GroupNorm(32 groups of 32 channels, biased variance, eps 1e-5: model.py:116,145,150) then SiLU:
-        //   o = acc + bias;  mean = sum32(o)/32;  o -= mean;  rstd = rsq(sum32(o^2)/32 + 1e-5);
-        //   y = o * (rstd * gamma) + beta;  out = y / (1 + exp(-y))
-        // written on float pairs so that it maps to v_pk_add / v_pk_mul / v_pk_fma_f32 (two results per VALU issue
-        // slot): VALU issue time is matrix-pipe time for the co-resident workgroup, and this epilogue is the largest
-        // non-MFMA item of the layer.
-        f32x2 p[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const f32x2 a2 = {acc[2 * k], acc[2 * k + 1]};
-            const f32x2 b2 = {b4[k >> 1][2 * (k & 1)], b4[k >> 1][2 * (k & 1) + 1]};
-            p[k] = a2 + b2;
-        }
-        f32x2 s2 = p[0];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) s2 += p[k];
-        float s = s2.x + s2.y;
-        s += __shfl_xor(s, 32);
-        const float mean = s * (1.0f / 32.0f);
-        const f32x2 m2 = {mean, mean};
-        f32x2 q2 = {0.0f, 0.0f};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            p[k] -= m2;
-            q2 = __builtin_elementwise_fma(p[k], p[k], q2);
-        }
-        float qs = q2.x + q2.y;
-        qs += __shfl_xor(qs, 32);
-#ifdef ZEDO_MUT_GN_EPS      // tools/mutation_check.py only: a deliberately wrong constant that the parity suite must catch
-        constexpr float GN_EPS = 2e-5f;
-#else
-        constexpr float GN_EPS = 1e-5f;
-#endif
-        const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(qs, 1.0f / 32.0f, GN_EPS));   // one fma, spelled out (-ffp-contract=off)
-        const f32x2 r2 = {rstd, rstd}, c2 = {-1.44269504088896340736f, -1.44269504088896340736f}, one2 = {1.0f, 1.0f};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const f32x2 g2 = {ga[k >> 1][2 * (k & 1)], ga[k >> 1][2 * (k & 1) + 1]};
-            const f32x2 e2 = {be[k >> 1][2 * (k & 1)], be[k >> 1][2 * (k & 1) + 1]};
-            const f32x2 y = __builtin_elementwise_fma(p[k], r2 * g2, e2);
-            const f32x2 t = y * c2;
-            const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + one2;
-            const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-            const f32x2 v = y * r;
-            o[2 * k] = v.x;
-            o[2 * k + 1] = v.y;
-        }
-        return;
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[4 * g + e] = acc[4 * g + e] + b4[g][e];
-    if constexpr (EPI == EPI_SDE) {            // x' = a x + c eps  (sampling.py:185-190 folded)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[e] *= sde_c;
-    } else if constexpr (EPI == EPI_BIAS_SILU) {      // built once per schedule: IEEE exp / divide
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[e] = o[e] / (1.0f + expf(-o[e]));
-    }
-}
 
 #ifdef ZEDO_UBENCH
 __device__ long long *g_timeline = nullptr;   // ubench only: 8 x int64 per workgroup {t0, t_loop, t_loop_end, t_end, hw_id, xcc_id}
@@ -493,6 +384,28 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
                     __syncthreads();
                 }
             }
+            if constexpr ((EPI == EPI_GN_SILU) && CPRW % 2 == 0 && (SR * CPRW / 2) % NT == 0) {
+                if (a.out_planes) {
+                    // split-fp16 planes output (zedo_tile.h): one thread = 8 consecutive channels = one 16-byte store of h
+                    // pieces and one of l pieces; the row keeps its 4 N bytes
+                    char *pbase = reinterpret_cast<char *>(a.out) + (size_t)m0 * a.ldo * 4u;
+#pragma unroll
+                    for (int pass = 0; pass < SR * CPRW / 2 / NT; ++pass) {
+                        const int qi = pass * NT + tid;
+                        const int sr = qi / (CPRW / 2), c = (qi % (CPRW / 2)) * 2;
+                        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(S + sr * BN + ((c ^ (sr & 7)) << 2));
+                        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(S + sr * BN + (((c + 1) ^ (sr & 7)) << 2));
+                        f16x8 h, l;
+                        split_f16x8(v0, v1, h, l);
+                        const int grow = (sr >> 5) * TM + j * 32 + (sr & 31), col = n0 + c * 4;
+                        const unsigned off = (unsigned)grow * (unsigned)a.ldo * 4u + (unsigned)((col >> 4) * 64 + ((col >> 3) & 1) * 16);
+                        *reinterpret_cast<f16x8 *>(pbase + off) = h;
+                        *reinterpret_cast<f16x8 *>(pbase + off + 32) = l;
+                    }
+                    if (j + 1 < TJ) __syncthreads();
+                    continue;
+                }
+            }
 #pragma unroll
             for (int pass = 0; pass < SR * CPRW / NT; ++pass) {
                 const int qi = pass * NT + tid;
@@ -529,7 +442,13 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int ncol = a.N / BN;
+#if defined(ZEDO_EXP_MAP) && ZEDO_EXP_MAP == 1
+    // experiment (tools/traffic_clock_experiment.sh): the naive map - column tile = block % ncol, so with 8 column tiles
+    // every XCD owns ONE column tile of W and every row tile of X is fetched by all 8 XCDs
+    layer_tile<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP>(a, (bid / ncol) * BM, (bid % ncol) * BN);
+#else
     layer_tile<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP>(a, (lid / ncol) * BM, (lid % ncol) * BN);
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1, int KSKIP = 0>

@@ -1,0 +1,314 @@
+// Hidden layers of the ZeDO score network (reference lib/algorithms/advanced/model.py:271-288) on the fp16 matrix pipe of
+// gfx950 at fp32-level accuracy ("f16x3", the opt-in math mode ZEDO_MATH_F16X3; the default stays exact fp32 MFMA,
+// zedo_gemm.hip).
+//
+//   out[m][n] = epilogue( unscale * sum_k X[m][k] * Ws[n][k] + bias[n] ),     Ws = W * 2^wshift
+//
+// Both operands travel as TWO fp16 pieces per element, a = ah + al + O(2^-24 |a|) (zedo_tile.h: the "planes" format,
+// 4 bytes per element like fp32), and a 16-deep k block of a 32x32 output tile costs three v_mfma_f32_32x32x16_f16:
+//     al.bh + ah.bl + ah.bh                     (al.bl <= 2^-24 relative is dropped)
+// with fp32 accumulation inside the MFMA.  Per product the error is that of ONE fp32 rounding - what a single step of the
+// exact-fp32 fma chain commits - and the sum over k takes 64 block additions instead of 1024 chained roundings: measured
+// max |y - y_fp64| of a whole GroupNorm + SiLU layer 1.4e-6 against 2.3e-6 for the exact-fp32 kernel on the same data
+// (tools/ubench/ubench_f16x3.hip).  fp16 has 5 exponent bits: W carries a per-layer power-of-two scale (max |w| -> [2^13,
+// 2^14)) undone exactly in the epilogue's first fma; activations are O(1..10) and unscaled; the matrix pipe honours fp16
+// denormals (probed), so tiny pieces cost an absolute 3e-8, not a flush.
+//
+// What bounds it (MI355X, tools/ubench/ubench_f16x3.hip, profiles/ubench_f16x3_r03.txt): three fp16 MFMAs are 96 matrix-
+// pipe cycles against 512 for the eight exact-fp32 MFMAs of the same block, but (i) under a dense fp16 MFMA stream power
+// management holds the shader clock at 1.7-1.85 GHz (2.36 for the fp32 kernel): the MFMA floor of a 50k-row layer is ~165 us,
+// not 127; (ii) the operands still cross L2 -> LDS at 4 bytes per element, and LDS-DMA sustains ~16 B/clk/CU (1 KB per
+// ~65 cycles of a CU's vector-memory path, 9.6 TB/s on the chip): 128x128 tiles move 3.2 GB per layer = the 335 us this
+// shape measures, i.e. the layer is bound by LDS-DMA throughput, no longer by the matrix pipe.
+//
+// Mapping, LDS layout and loop are the exact-fp32 kernel's (zedo_gemm.hip) with 64-byte LDS rows:
+//   i = output CHANNEL (rows of W, MFMA A operand), j = BATCH ROW (rows of X, B operand); lane (li, kh) holds k = 8 kh .. 8 kh + 7
+//   of row li: one ds_read_b128 per plane; chunk c = 2 plane + kh of LDS row r sits at position c ^ ((r >> 2) & 3), which
+//   makes every 16-lane group of a ds_read_b128 hit 16 distinct slots (SQ_LDS_BANK_CONFLICT = 0, measured).
+#include "zedo_internal.h"
+#include "zedo_tile.h"
+
+#include <atomic>
+
+namespace zedo {
+
+// fp32 [rows][cols] (row stride ld) * scale -> planes
+__global__ void split_planes_kernel(const float *__restrict__ src, int rows, int cols, int ld, float scale,
+                                    uint16_t *__restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread = 8 consecutive columns
+    const int per_row = cols / 8;
+    if (i >= (size_t)rows * per_row) return;
+    const int r = (int)(i / per_row), c = (int)(i % per_row) * 8;
+    const float *s = src + (size_t)r * ld + c;
+    f32x4 v0 = *reinterpret_cast<const f32x4 *>(s), v1 = *reinterpret_cast<const f32x4 *>(s + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v0[e] *= scale; v1[e] *= scale; }
+    f16x8 h, l;
+    split_f16x8(v0, v1, h, l);
+    char *d = reinterpret_cast<char *>(dst) + (size_t)r * cols * 4 + (c >> 4) * 64 + ((c >> 3) & 1) * 16;
+    *reinterpret_cast<f16x8 *>(d) = h;
+    *reinterpret_cast<f16x8 *>(d + 32) = l;
+}
+
+hipError_t launch_split_planes(const float *src, int rows, int cols, int ld, float scale, uint16_t *dst, hipStream_t st) {
+    if (cols % 16 || ld % 4) return hipErrorInvalidValue;
+    const size_t n = (size_t)rows * (cols / 8);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, rows, cols, ld, scale, dst);
+    return hipGetLastError();
+}
+
+// One BM x BN output tile.  WM x WN waves, each TM x TN = (BM/WM) x (BN/WN); ring of two 16-k blocks.
+template <int BM, int BN, int WM, int WN, int EPI>
+__device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0, const int n0) {
+    constexpr int NW = WM * WN, NT = NW * 64;
+    constexpr int TM = BM / WM, TN = BN / WN, TJ = TM / 32, TI = TN / 32;
+    constexpr int RB = 64, CPR = 4;                                   // bytes / 16-byte chunks per LDS row per k block
+    constexpr int IA = BN * CPR / 64 / NW, IB = BM * CPR / 64 / NW, IPW = IA + IB;    // DMA instructions (1 KB) per wave per block
+    static_assert(TM % 32 == 0 && TN % 32 == 0 && IA >= 1 && IB >= 1 && (BN * CPR) % (64 * NW) == 0 && (BM * CPR) % (64 * NW) == 0, "tile");
+    constexpr int SLOT = (BN + BM) * RB;                              // one ring slot: [BN rows of W][BM rows of X]
+    constexpr int SR = WM * 32;                                       // epilogue stage rows per phase
+    constexpr int RING_B = 2 * SLOT, STAGE_B = SR * BN * 4, BODY_B = RING_B > STAGE_B ? RING_B : STAGE_B;
+
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    float *Ps = reinterpret_cast<float *>(smem16 + BODY_B);           // [3][BN] bias | gamma | beta
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN, li = lane & 31, kh = lane >> 5;
+    const size_t xstride = (size_t)a.K * 4;                           // bytes per operand row (planes: 4 bytes per element)
+    const char *Wbase = reinterpret_cast<const char *>(a.W) + (size_t)n0 * xstride;
+    const char *Xbase = reinterpret_cast<const char *>(a.X) + (size_t)m0 * xstride;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem16;
+
+    // DMA instruction p of this wave moves the 16-byte chunks g = (wid * I + p) * 64 + lane of the tile's block: LDS row
+    // g / 4, position g % 4, which holds source chunk (g % 4) ^ swz(row)
+    unsigned woff[IA], xoff[IB];
+#pragma unroll
+    for (int p = 0; p < IA; ++p) { const int g = (wid * IA + p) * 64 + lane, r = g / CPR; woff[p] = (unsigned)(r * xstride + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
+#pragma unroll
+    for (int p = 0; p < IB; ++p) { const int g = (wid * IB + p) * 64 + lane, r = g / CPR; xoff[p] = (unsigned)(r * xstride + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
+    auto dma = [&](int kb, int slot) {
+        const char *wk = Wbase + (size_t)kb * RB, *xk = Xbase + (size_t)kb * RB;
+#pragma unroll
+        for (int p = 0; p < IA; ++p) dma16(wk, woff[p], lds0 + slot * SLOT + (wid * IA + p) * 1024);
+#pragma unroll
+        for (int p = 0; p < IB; ++p) dma16(xk, xoff[p], lds0 + slot * SLOT + BN * RB + (wid * IB + p) * 1024);
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragments {A.h, A.l, B.h, B.l} of one block, two register sets (the next block's reads are issued in front of this
+    // block's MFMAs and pinned there: left alone the compiler sinks them to their first use)
+    f16x8 fa[2][TI][2], fb[2][TJ][2];
+    const int fs = (li >> 2) & 3;                  // tile bases are multiples of 32 rows: swz(row) == swz(li)
+    auto fread = [&](int set, int slot) {
+        const char *As = smem16 + slot * SLOT + (wn * TN + li) * RB;
+        const char *Bs = smem16 + slot * SLOT + BN * RB + (wm * TM + li) * RB;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fa[set][i][pl] = *reinterpret_cast<const f16x8 *>(As + i * 32 * RB + (((pl * 2 + kh) ^ fs) * 16));
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fb[set][j][pl] = *reinterpret_cast<const f16x8 *>(Bs + j * 32 * RB + (((pl * 2 + kh) ^ fs) * 16));
+    };
+    // product-major: consecutive MFMAs go to different accumulators; the small terms first.  The ORDER (lh, hl, hh per
+    // block, blocks ascending) is the same for every tile shape: two launches of the same rows agree bit for bit.
+    auto mma = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][1], fb[set][j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][0], fb[set][j][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][0], fb[set][j][0], acc[i][j], 0, 0, 0);
+    };
+
+    if (tid < BN / 4) {       // epilogue parameters -> LDS once
+        *reinterpret_cast<f32x4 *>(Ps + tid * 4) = *reinterpret_cast<const f32x4 *>(a.bias + n0 + tid * 4);
+        *reinterpret_cast<f32x4 *>(Ps + BN + tid * 4) = *reinterpret_cast<const f32x4 *>(a.gamma + n0 + tid * 4);
+        *reinterpret_cast<f32x4 *>(Ps + 2 * BN + tid * 4) = *reinterpret_cast<const f32x4 *>(a.beta + n0 + tid * 4);
+    }
+    const int KB = a.K / 16;                       // even (checked at launch): the ring slot is a compile-time constant
+    dma(0, 0);
+    dma(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");      // block 0 landed
+    __syncthreads();
+    fread(0, 0);
+    //   block kb in slot kb & 1, its fragments in set kb & 1:
+    //       vmcnt(0); barrier      <- every wave has read block kb (its fragments are in registers), block kb+1 has landed
+    //       DMA(block kb+2 -> slot of kb);  read(block kb+1) -> the other set;  MFMA(block kb)
+    for (int kb0 = 0; kb0 < KB; kb0 += 2) {
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+            const int kb = kb0 + slot;
+            // hipcc does not count the LDS-DMA in its vmcnt bookkeeping: wait explicitly
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            dma(min(kb + 2, KB - 1), slot);        // branch-free: past the end it refills a slot nobody reads again
+            fread(slot ^ 1, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(slot);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();           // drain the trailing DMA before the ring becomes the epilogue stage
+
+    // ---- epilogue: GroupNorm + SiLU on the accumulators, staged through the LDS row-wise (chunk c of stage row sr at
+    //      position c ^ (sr & 7), as in zedo_gemm.hip), then per thread 16 consecutive channels of a row: [residual from
+    //      its planes +] either 64 bytes of fp32 or 32 + 32 bytes of fp16 pieces - the same 64 bytes of the row either way
+    {
+        constexpr int CG = BN / 16;              // 16-channel groups per stage row
+        static_assert((SR * CG) % NT == 0 || NT % (SR * CG) == 0, "write-out shape");
+        float *S = reinterpret_cast<float *>(smem16);
+        char *obase = reinterpret_cast<char *>(a.out) + (size_t)m0 * a.N * 4 + (size_t)n0 * 4;
+        const char *rbase = reinterpret_cast<const char *>(a.res) + (size_t)m0 * a.N * 4 + (size_t)n0 * 4;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                float o[16];
+                f32x4 b4[4], ga[4], be[4];
+                const float *pc = Ps + wn * TN + i * 32 + 4 * kh;   // channel of accumulator r: + (r&3) + 8*(r>>2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    b4[g] = *reinterpret_cast<const f32x4 *>(pc + 8 * g);
+                    ga[g] = *reinterpret_cast<const f32x4 *>(pc + BN + 8 * g);
+                    be[g] = *reinterpret_cast<const f32x4 *>(pc + 2 * BN + 8 * g);
+                }
+                epilogue_values<EPI_GN_SILU, true>(acc[i][j], b4, ga, be, 0.f, o, a.unscale);
+                float *srow = S + (wm * 32 + li) * BN;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = (wn * TN + i * 32 + 8 * g + 4 * kh) >> 2;
+                    const f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+                    *reinterpret_cast<f32x4 *>(srow + ((c ^ (li & 7)) << 2)) = v;
+                }
+            }
+            __syncthreads();
+            for (int qi = tid; qi < SR * CG; qi += NT) {
+                const int sr = qi / CG, cg = qi % CG;
+                const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
+                const unsigned off = (unsigned)grow * (unsigned)a.N * 4u + (unsigned)cg * 64u;
+                f32x4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4 *>(S + sr * BN + (((cg * 4 + q) ^ (sr & 7)) << 2));
+                if constexpr (EPI == EPI_GN_SILU_RES) {            // h = h + h2 (model.py:288): h from its planes, exactly h + l
+                    const f16x8 rh0 = *reinterpret_cast<const f16x8 *>(rbase + off), rh1 = *reinterpret_cast<const f16x8 *>(rbase + off + 16);
+                    const f16x8 rl0 = *reinterpret_cast<const f16x8 *>(rbase + off + 32), rl1 = *reinterpret_cast<const f16x8 *>(rbase + off + 48);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[0][e] += join_f16(rh0[e], rl0[e]);     v[1][e] += join_f16(rh0[4 + e], rl0[4 + e]);
+                        v[2][e] += join_f16(rh1[e], rl1[e]);     v[3][e] += join_f16(rh1[4 + e], rl1[4 + e]);
+                    }
+                }
+                if (a.out_f32) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(obase + off + 16 * q) = v[q];
+                } else {
+                    f16x8 h0, l0, h1, l1;
+                    split_f16x8(v[0], v[1], h0, l0);
+                    split_f16x8(v[2], v[3], h1, l1);
+                    *reinterpret_cast<f16x8 *>(obase + off) = h0;
+                    *reinterpret_cast<f16x8 *>(obase + off + 16) = h1;
+                    *reinterpret_cast<f16x8 *>(obase + off + 32) = l0;
+                    *reinterpret_cast<f16x8 *>(obase + off + 48) = l1;
+                }
+            }
+            if (j + 1 < TJ) __syncthreads();
+        }
+    }
+}
+
+// block -> tile, XCD aware (the hardware places block b on XCD b % 8): every XCD gets a contiguous range of tiles so that
+// the column tiles of one row tile share one L2 (same map as zedo_gemm.hip)
+template <int BM, int BN, int WM, int WN, int EPI>
+__device__ __forceinline__ void layer16_body(const Layer16Args &a, const int bid, const int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int ncol = a.N / BN;
+    layer16_tile<BM, BN, WM, WN, EPI>(a, (lid / ncol) * BM, (lid % ncol) * BN);
+}
+
+// One launch, two tile shapes (as layer_pair_kernel of zedo_gemm.hip): workgroups [0, nbig) run 128x128 tiles on the rows
+// that fill whole rounds of the chip, the rest 64x128 tiles on the remainder rows, which back-fill CUs as the big tiles
+// drain.  Either count may be zero.  Three workgroups per CU (35 KB of LDS, <= 168 registers).
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void layer16_pair_kernel(Layer16Args big, Layer16Args small, int nbig) {
+    long long c0 = 0, w0 = 0;
+    const bool probe = big.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    if (probe) { c0 = clock64(); w0 = wall_clock64(); }
+    if ((int)blockIdx.x < nbig) layer16_body<128, 128, 2, 2, EPI>(big, blockIdx.x, nbig);
+    else layer16_body<64, 128, 2, 2, EPI>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+    if (probe) { big.clk[0] = clock64() - c0; big.clk[1] = wall_clock64() - w0; }
+}
+
+constexpr int MAX_DEVICES16 = 16;
+
+template <int EPI>
+static hipError_t launch_pair16(const Layer16Args &big, const Layer16Args &small, hipStream_t st) {
+    constexpr size_t ring_big = 2 * (128 + 128) * 64, stage = (size_t)64 * 128 * 4;
+    constexpr size_t lds = (ring_big > stage ? ring_big : stage) + 3 * 128 * sizeof(float);
+    auto kern = layer16_pair_kernel<EPI>;
+    static std::atomic<bool> attr_done[MAX_DEVICES16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= MAX_DEVICES16) dev = 0;
+    if (!attr_done[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[dev].store(true, std::memory_order_release);
+    }
+    const int nbig = (big.Mp / 128) * (big.N / 128), nsmall = (small.Mp / 64) * (small.N / 128);
+    if (nbig + nsmall == 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(nbig + nsmall), dim3(256), lds, st, big, small, nbig);
+    return hipGetLastError();
+}
+
+static Layer16Args rows_of16(const Layer16Args &a, int row0, int rows) {
+    Layer16Args b = a;
+    b.X = a.X + (size_t)row0 * a.K * 2;            // uint16 units: 4 bytes per element
+    b.out = reinterpret_cast<char *>(a.out) + (size_t)row0 * a.N * 4;
+    if (a.res) b.res = a.res + (size_t)row0 * a.N * 2;
+    b.Mp = rows;
+    return b;
+}
+
+hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st) {
+    if (a.Mp <= 0 || a.Mp % 64 || a.N % 128 || a.K % 32 || !a.X || !a.W || !a.out) return hipErrorInvalidValue;
+    if (epilogue == EPI_GN_SILU_RES && !a.res) return hipErrorInvalidValue;
+    static std::atomic<int> cus_cached{0};
+    int cus = cus_cached.load(std::memory_order_relaxed);
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        (void)hipGetDevice(&dev);
+        cus = (hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+        cus_cached.store(cus, std::memory_order_relaxed);
+    }
+    // 128x128 tiles on the rows that fill whole rounds of 3 workgroups per CU; the remainder (and every batch smaller than
+    // one round) on 64x128 tiles: finer tiles spread a short launch over more CUs
+    const int per_round = cus * 3 * 128 / (a.N / 128);
+    const int rows_big = (a.Mp / per_round) * per_round, rows_small = a.Mp - rows_big;
+    const Layer16Args big = rows_of16(a, 0, rows_big), small = rows_of16(a, rows_big, rows_small);
+    switch (epilogue) {
+        case EPI_GN_SILU: return launch_pair16<EPI_GN_SILU>(big, small, st);
+        case EPI_GN_SILU_RES: return launch_pair16<EPI_GN_SILU_RES>(big, small, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace zedo

@@ -34,6 +34,7 @@ struct LayerArgs {
     int N;               // multiple of the tile's BN
     int Mp;              // multiple of the tile's BM
     float sde_a, sde_c;  // EPI_SDE
+    int out_planes;      // GN epilogues with N % 16 == 0: write the output in the split-fp16 planes format (zedo_tile.h) instead of fp32
     int kzero8;          // K == 64 only: columns k = 56..63 of X and W are zero padding (their MFMAs are skipped)
     long long *clk;      // diagnostic (may be null): workgroup 0 writes {shader cycles, 100 MHz wall ticks} it spent in the tile
     // EPI_SDE only, optional (rp_geom != nullptr): the reprojection correction of the NEXT loop iteration
@@ -46,6 +47,23 @@ struct LayerArgs {
 };
 
 hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st);
+
+// One hidden layer on the fp16 matrix pipe (zedo_gemm16.hip): out = epilogue(X . W^T * unscale + bias), X and W in the
+// split-fp16 planes format, three 32x32x16 fp16 MFMAs (hl, lh, hh) per 16-k block, fp32 accumulation.
+struct Layer16Args {
+    const uint16_t *X;      // planes [Mp][K/16][2][16]
+    const uint16_t *W;      // planes [N][K/16][2][16] of W * 2^wshift
+    const float *bias, *gamma, *beta;   // [N]
+    float unscale;          // 2^-wshift (exact)
+    const uint16_t *res;    // EPI_GN_SILU_RES: residual planes [Mp][N/16][2][16]; may be the output buffer (in place)
+    void *out;              // planes [Mp][N/16][2][16] (out_f32 == 0) or fp32 [Mp][N] (out_f32 != 0): the same 4 N bytes per row
+    int out_f32;
+    int K, N, Mp;           // K % 32 == 0, N % 128 == 0, Mp % 64 == 0
+    long long *clk;         // diagnostic (may be null), as in LayerArgs
+};
+hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st);
+// fp32 [rows][cols] (row stride ld floats) * scale -> planes [rows][cols/16][2][16]; cols % 16 == 0
+hipError_t launch_split_planes(const float *src, int rows, int cols, int ld, float scale, uint16_t *dst, hipStream_t st);
 hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStream_t st);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -1,0 +1,141 @@
+// Device helpers shared by the two dense-layer translation units (zedo_gemm.hip: exact-fp32 MFMA tiles; zedo_gemm16.hip:
+// split-fp16 tiles): the LDS-DMA issue helper and the GroupNorm / SiLU / SDE epilogue arithmetic.  gfx950 only.
+#pragma once
+#include "zedo_internal.h"
+
+namespace zedo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// ---- split-fp16 activation format ("planes") --------------------------------------------------------------------
+// An fp32 value a is carried as two fp16 pieces, a = h + l + O(2^-24 |a|): h = fp16(a), l = fp16(a - h), both round to
+// nearest even (11 significant bits each, signed: 23 bits of a).  A row of C channels is stored as
+//     P[row][C/16][2 planes][16] fp16        (64 bytes per 16 channels: 32 B of h, 32 B of l; 4 bytes per element)
+// which is exactly the operand layout the 32x32x16 fp16 MFMA tiles of zedo_gemm16.hip stream through the LDS.
+// fp16 tops out at 65504: activations of this network are SiLU(GroupNorm(.)) outputs and their residual sums, bounded
+// by (|gamma| sqrt(31) + |beta|) per layer - O(10) - and are stored unscaled; pieces below 6.1e-5 are fp16 denormals,
+// which the gfx950 matrix pipe honours (tools/ubench/ubench_f16x3.hip probes it): absolute error <= 3e-8 per element.
+__device__ __forceinline__ void split_f16x8(const f32x4 &v0, const f32x4 &v1, f16x8 &h, f16x8 &l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 h0 = (_Float16)v0[e], h1 = (_Float16)v1[e];
+        h[e] = h0; h[4 + e] = h1;
+        l[e] = (_Float16)(v0[e] - (float)h0); l[4 + e] = (_Float16)(v1[e] - (float)h1);
+    }
+}
+// the value the planes stand for: h + l is exact in fp32 (the pieces do not overlap)
+__device__ __forceinline__ float join_f16(_Float16 h, _Float16 l) { return (float)h + (float)l; }
+
+
+// global -> LDS DMA of 64 x 16 bytes: source = wave-uniform 64-bit base + per-lane 32-bit byte offset, destination =
+// wave-uniform LDS byte address + lane*16.  Inline asm because hipcc materialises base + zext(offset) with a 64-bit
+// VALU add per instruction inside the K loop, and VALU issue time is matrix-pipe time here.  M0 (the LDS
+// destination) is compiler-reserved: it is saved and restored inside the statement.  hipcc does not count this load
+// in its vmcnt bookkeeping - every consumer below sits behind an explicit s_waitcnt vmcnt + barrier.
+#ifdef ZEDO_EXP_XSC1   // experiment: activation (X) tiles fetched past the per-XCD L2's non-coherent lines
+#if ZEDO_EXP_XSC1 == 1
+#define ZEDO_XMOD "sc1"
+#elif ZEDO_EXP_XSC1 == 2
+#define ZEDO_XMOD "sc0 sc1"
+#else
+#define ZEDO_XMOD "nt"
+#endif
+__device__ __forceinline__ void dma16x(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 " ZEDO_XMOD "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(sbase), "v"(voff), "s"(lds_byte_addr)
+                 : "memory");
+}
+#else
+#define dma16x dma16
+#endif
+__device__ __forceinline__ void dma16(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(sbase), "v"(voff), "s"(lds_byte_addr)
+                 : "memory");
+}
+
+__device__ __forceinline__ float silu_fast(float y) {
+    // y * sigmoid(y) with hardware exp2 / rcp (each <= 1 ulp): |rel err| <= ~3e-7
+    return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.44269504088896340736f));
+}
+
+// Per-element part of the epilogue for one 32(channel) x 32(row) accumulator tile; lane = (batch row li,
+// channel half kh), o[4g+e] belongs to channel cbase + 8g + e.  The residual / previous-x term is added by
+// the caller from the LDS stage (EPI_GN_SILU_RES: o += h;  EPI_SDE: o += sde_a * x).
+// SCALED (split-fp16 tiles, whose W operand carries a power-of-two scale): acc * acc_scale + bias in one fma.
+template <int EPI, bool SCALED = false>
+__device__ __forceinline__ void epilogue_values(const f32x16 &acc, const f32x4 (&b4)[4], const f32x4 (&ga)[4],
+                                                const f32x4 (&be)[4], float sde_c, float (&o)[16], float acc_scale = 1.0f) {
+    if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
+        // GroupNorm(32 groups of 32 channels, biased variance, eps 1e-5: model.py:116,145,150) then SiLU:
+        //   o = acc + bias;  mean = sum32(o)/32;  o -= mean;  rstd = rsq(sum32(o^2)/32 + 1e-5);
+        //   y = o * (rstd * gamma) + beta;  out = y / (1 + exp(-y))
+        // written on float pairs so that it maps to v_pk_add / v_pk_mul / v_pk_fma_f32 (two results per VALU issue
+        // slot): VALU issue time is matrix-pipe time for the co-resident workgroup, and this epilogue is the largest
+        // non-MFMA item of the layer.
+        f32x2 p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x2 a2 = {acc[2 * k], acc[2 * k + 1]};
+            const f32x2 b2 = {b4[k >> 1][2 * (k & 1)], b4[k >> 1][2 * (k & 1) + 1]};
+            if constexpr (SCALED) p[k] = __builtin_elementwise_fma(a2, (f32x2){acc_scale, acc_scale}, b2);
+            else p[k] = a2 + b2;
+        }
+        f32x2 s2 = p[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s2 += p[k];
+        float s = s2.x + s2.y;
+        s += __shfl_xor(s, 32);
+        const float mean = s * (1.0f / 32.0f);
+        const f32x2 m2 = {mean, mean};
+        f32x2 q2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            p[k] -= m2;
+            q2 = __builtin_elementwise_fma(p[k], p[k], q2);
+        }
+        float qs = q2.x + q2.y;
+        qs += __shfl_xor(qs, 32);
+#ifdef ZEDO_MUT_GN_EPS      // tools/mutation_check.py only: a deliberately wrong constant that the parity suite must catch
+        constexpr float GN_EPS = 2e-5f;
+#else
+        constexpr float GN_EPS = 1e-5f;
+#endif
+        const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(qs, 1.0f / 32.0f, GN_EPS));   // one fma, spelled out (-ffp-contract=off)
+        const f32x2 r2 = {rstd, rstd}, c2 = {-1.44269504088896340736f, -1.44269504088896340736f}, one2 = {1.0f, 1.0f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x2 g2 = {ga[k >> 1][2 * (k & 1)], ga[k >> 1][2 * (k & 1) + 1]};
+            const f32x2 e2 = {be[k >> 1][2 * (k & 1)], be[k >> 1][2 * (k & 1) + 1]};
+            const f32x2 y = __builtin_elementwise_fma(p[k], r2 * g2, e2);
+            const f32x2 t = y * c2;
+            const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + one2;
+            const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+            const f32x2 v = y * r;
+            o[2 * k] = v.x;
+            o[2 * k + 1] = v.y;
+        }
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[4 * g + e] = acc[4 * g + e] + b4[g][e];
+    if constexpr (EPI == EPI_SDE) {            // x' = a x + c eps  (sampling.py:185-190 folded)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] *= sde_c;
+    } else if constexpr (EPI == EPI_BIAS_SILU) {      // built once per schedule: IEEE exp / divide
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = o[e] / (1.0f + expf(-o[e]));
+    }
+}
+
+
+}  // namespace zedo

@@ -88,7 +88,7 @@ class ScoreModelFC_Adv(nn.Module):
 
     def hip_weights(self):
         import zedo_hip
-        key = self._version()
+        key = (self._version(), zedo_hip.default_math())      # ZEDO_MATH may change between calls (tests run both modes)
         if self._packed is None or self._packed[0] != key:
             sd = {k: v for k, v in self.state_dict().items() if k != "sigmas"}
             self._packed = (key, zedo_hip.Weights(sd, self.n_joints, self.joint_dim, self.hidden_dim, self.embed_dim,

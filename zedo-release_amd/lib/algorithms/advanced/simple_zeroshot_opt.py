@@ -122,7 +122,7 @@ def gradient_field_gen(key2d, key3d, K, noise_type=None, t=None, conf=None, retu
         geom, singular = _rays(uv, Kc, None)
     if t is None:
         if singular:          # torch.inverse(AtA) of the reference raises on a singular system (:89-92)
-            raise RuntimeError(zedo_hip.SINGULAR_MSG.format(n=singular))
+            raise torch.linalg.LinAlgError(zedo_hip.SINGULAR_MSG.format(n=singular))
         T = torch.empty((B, 3), dtype=torch.float32, device=x.device)      # written by the kernel (solve_T)
         g = zedo_hip.reproj_grad(x, geom, T, True)
     else:

@@ -36,6 +36,8 @@ SIGNATURES = {
     "zedo_error_string": (ctypes.c_char_p, [_i]),
     "zedo_weights_create": (_i, [_vp, _sz, _i, _i, _i, _i, _i, _vp, ctypes.POINTER(_vp)]),
     "zedo_weights_destroy": (None, [_vp]),
+    "zedo_weights_set_math": (_i, [_vp, _i, _vp]),
+    "zedo_weights_get_math": (_i, [_vp]),
     "zedo_schedule_create": (_i, [_vp, _vp, _i, _f, _f, _f, _i, _vp, ctypes.POINTER(_vp)]),
     "zedo_schedule_destroy": (None, [_vp]),
     "zedo_schedule_read": (_i, [_vp, _vp, _vp, _vp]),
@@ -115,11 +117,24 @@ def param_names(n_blocks=2):
     return names + ["post_dense.weight", "post_dense.bias"]
 
 
+MATH_MODES = {"f32": 0, "f16x3": 1}      # ZEDO_MATH_F32 / ZEDO_MATH_F16X3 of include/zedo_hip.h
+
+
+def default_math():
+    """The arithmetic of the hidden layers for handles created from now on: environment ZEDO_MATH = f32 (default: exact
+    fp32 MFMA) | f16x3 (split-fp16 operands on the fp16 matrix pipe, fp32-level accuracy; opt-in)."""
+    m = os.environ.get("ZEDO_MATH", "f32").strip().lower() or "f32"
+    if m not in MATH_MODES:
+        raise ZedoError(f"ZEDO_MATH={m!r}: expected one of {sorted(MATH_MODES)}")
+    return m
+
+
 class Weights:
-    """Device copy of a ScoreModelFC_Adv state dict, repacked for the kernels (zedo_weights_create)."""
+    """Device copy of a ScoreModelFC_Adv state dict, repacked for the kernels (zedo_weights_create).
+    math: "f32" | "f16x3" | None (= default_math(), i.e. the ZEDO_MATH environment variable)."""
 
     def __init__(self, state_dict, n_joints=N_JOINTS, joint_dim=JOINT_DIM, hidden=HIDDEN_DIM, embed=EMBED_DIM,
-                 n_blocks=2):
+                 n_blocks=2, math=None):
         _need_gpu()
         flat = []
         for name in param_names(n_blocks):
@@ -132,6 +147,14 @@ class Weights:
         _check(_lib.zedo_weights_create(flat.ctypes.data_as(_vp), flat.size, n_joints, joint_dim, hidden, embed,
                                         n_blocks, _stream(), ctypes.byref(self._h)))
         self.n_joints, self.joint_dim, self.hidden, self.embed, self.n_blocks = n_joints, joint_dim, hidden, embed, n_blocks
+        self.set_math(default_math() if math is None else math)
+
+    def set_math(self, math):
+        if math not in MATH_MODES:
+            raise ZedoError(f"math mode {math!r}: expected one of {sorted(MATH_MODES)}")
+        _check(_lib.zedo_weights_set_math(self._h, MATH_MODES[math], _stream()))
+        self.math = math
+        return self
 
     def __del__(self):
         h = getattr(self, "_h", None)
