@@ -7,5 +7,5 @@ trap restore EXIT
 for v in "$@"; do
   (cd zedo-release_amd/csrc && touch zedo_gemm.hip && make EXTRA="$v" 2>&1 | grep -E "error" )
   echo "== build [$v]"
-  python bench.py --no-cpu-baseline --steps ${AB_STEPS:-2} --warmup 1 2>&1 | tail -1 | python -c "$P"
+  python bench.py --no-cpu-baseline --no-alt-mode --steps ${AB_STEPS:-2} --warmup 1 2>&1 | tail -1 | python -c "$P"
 done

@@ -20,12 +20,12 @@ for round in 1 2; do
     (cd $ROOT/zedo-release_amd/csrc && touch zedo_gemm.hip && make EXTRA="$v" 2>&1 | grep -E "error")
     echo "== round $round  [${NAMES[$i]}]  EXTRA='$v'"
     for rep in 1 2; do
-      python3 $ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1 2>&1 | python3 -c "$P"
+      python3 $ROOT/bench.py --no-cpu-baseline --no-alt-mode --steps 2 --warmup 1 2>&1 | python3 -c "$P"
     done
     if [ $round = 1 ]; then
       cd /tmp; rm -rf /tmp/ztc_f /tmp/ztc_w
-      rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/ztc_f -o f -- python3 $ROOT/bench.py --steps 1 --warmup 0 --oil 40 --no-cpu-baseline > /dev/null 2>&1
-      rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/ztc_w -o w -- python3 $ROOT/bench.py --steps 1 --warmup 0 --oil 40 --no-cpu-baseline > /dev/null 2>&1
+      rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/ztc_f -o f -- python3 $ROOT/bench.py --steps 1 --warmup 0 --oil 40 --no-cpu-baseline --no-alt-mode > /dev/null 2>&1
+      rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/ztc_w -o w -- python3 $ROOT/bench.py --steps 1 --warmup 0 --oil 40 --no-cpu-baseline --no-alt-mode > /dev/null 2>&1
       cd $ROOT
       python3 tools/pmc_summary.py 50750 /tmp/ztc_${i}.json $(find /tmp/ztc_f /tmp/ztc_w -name '*_results.db') 2>&1 | tail -1
     fi

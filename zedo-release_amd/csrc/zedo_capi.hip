@@ -32,9 +32,9 @@ struct zedo_weights {
     std::mutex scratch_mu;
     // ZEDO_MATH_F16X3 (zedo_weights_set_math): the four hidden weights as split-fp16 planes of W * 2^wshift
     int math;
-    uint16_t *d_W16;            // [4][H][H/16][2][16]
-    float wmax_hid[4];          // max |w| per hidden layer (from the host copy at create time)
-    float unscale[4];           // 2^-wshift per hidden layer
+    uint16_t *d_W16;            // hidden [4][H][H/16][2][16] | pre_dense [H][4][2][16] | post_dense [XLD][H/16][2][16]
+    float wmax_hid[6];          // max |w| of the four hidden layers, pre_dense, post_dense (from the host copy at create time)
+    float unscale[6];           // 2^-wshift, same order
 };
 
 struct zedo_schedule {
@@ -198,12 +198,13 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
 
     const float *p = h_params;
     auto next = [&](size_t n) { const float *q = p; p += n; return q; };
-    float wmax_hid_tmp[4] = {0, 0, 0, 0};
+    float wmax_hid_tmp[6] = {0, 0, 0, 0, 0, 0};
     // pre_dense
     const float *w_pre = next(H * J3), *b_pre = next(H), *w_pre_t = next(H * E), *b_pre_t = next(H);
     const float *g_pre = next(H), *be_pre = next(H);
     const float *w_s = next(E * E), *b_s = next(E);
     for (size_t n = 0; n < H; ++n) memcpy(&img[o_Wpre + n * XLD], w_pre + n * J3, sizeof(float) * J3);
+    for (size_t q = 0; q < H * J3; ++q) wmax_hid_tmp[4] = std::fmax(wmax_hid_tmp[4], std::fabs(w_pre[q]));
     memcpy(&img[o_gamma], g_pre, sizeof(float) * H);
     memcpy(&img[o_beta], be_pre, sizeof(float) * H);
     memcpy(&img[o_Ws], w_s, sizeof(float) * E * E);
@@ -225,6 +226,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     }
     const float *w_post = next((size_t)J3 * H), *b_post = next(J3);
     memcpy(&img[o_Wpost], w_post, sizeof(float) * J3 * H);
+    for (size_t q = 0; q < (size_t)J3 * H; ++q) wmax_hid_tmp[5] = std::fmax(wmax_hid_tmp[5], std::fabs(w_post[q]));
     memcpy(&img[o_bpost], b_post, sizeof(float) * J3);
 
     zedo_weights *w = new (std::nothrow) zedo_weights();
@@ -232,7 +234,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     w->J3 = J3; w->hidden = hidden; w->embed = embed; w->n_blocks = n_blocks;
     w->d_scratch = nullptr;
     w->math = ZEDO_MATH_F32; w->d_W16 = nullptr;
-    for (int l = 0; l < 4; ++l) { w->wmax_hid[l] = wmax_hid_tmp[l]; w->unscale[l] = 1.0f; }
+    for (int l = 0; l < 6; ++l) { w->wmax_hid[l] = wmax_hid_tmp[l]; w->unscale[l] = 1.0f; }
     hipError_t e = hipMalloc(&w->d_all, off * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&w->d_scratch, sizeof(float) * ((size_t)2 * ROW_PAD * EMB + ROW_PAD));
     if (e != hipSuccess) { (void)hipFree(w->d_all); delete w; return (int)e; }
@@ -266,19 +268,22 @@ extern "C" int zedo_weights_set_math(zedo_weights_t *w, int mode, void *stream) 
     if (!w || (mode != ZEDO_MATH_F32 && mode != ZEDO_MATH_F16X3)) return ZEDO_E_BADARG;
     if (mode == ZEDO_MATH_F16X3 && !w->d_W16) {
         hipStream_t st = (hipStream_t)stream;
-        for (int l = 0; l < 4; ++l)
+        for (int l = 0; l < 6; ++l)
             if (!std::isfinite(w->wmax_hid[l])) return ZEDO_E_BADARG;          // a non-finite weight has no fp16 image
-        const size_t per = (size_t)HID * HID * 2;                                 // uint16 per layer
-        HIPCHK(hipMalloc(&w->d_W16, sizeof(uint16_t) * 4 * per));
+        const size_t per = (size_t)HID * HID * 2;                                 // uint16 per hidden layer
+        HIPCHK(hipMalloc(&w->d_W16, sizeof(uint16_t) * (4 * per + (size_t)HID * XLD * 2 + (size_t)XLD * HID * 2)));
         hipError_t e = hipSuccess;
-        for (int l = 0; l < 4 && e == hipSuccess; ++l) {
+        for (int l = 0; l < 6 && e == hipSuccess; ++l) {
             // power-of-two scale that puts max |w| into [2^13, 2^14): the low pieces of all but vanishing weights stay normal
             int ex = 0;
             const float wm = w->wmax_hid[l];
             if (wm > 0.f) (void)std::frexp(wm, &ex);                             // wm = f * 2^ex, f in [0.5, 1)
             const int shift = wm > 0.f ? 14 - ex : 0;
             w->unscale[l] = std::ldexp(1.0f, -shift);
-            e = launch_split_planes(w->W_hid[l], HID, HID, HID, std::ldexp(1.0f, shift), w->d_W16 + (size_t)l * per, st);
+            const float sc = std::ldexp(1.0f, shift);
+            if (l < 4) e = launch_split_planes(w->W_hid[l], HID, HID, HID, sc, w->d_W16 + (size_t)l * per, st);
+            else if (l == 4) e = launch_split_planes(w->W_pre, HID, XLD, XLD, sc, w->d_W16 + 4 * per, st);
+            else e = launch_split_planes(w->W_post, XLD, HID, HID, sc, w->d_W16 + 4 * per + (size_t)HID * XLD * 2, st);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { (void)hipFree(w->d_W16); w->d_W16 = nullptr; return (int)e; }
@@ -413,15 +418,24 @@ static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad
     a.X = xpad; a.ldx = XLD; a.W = w->W_pre; a.ldw = XLD; a.K = XLD; a.N = HID;
     a.kzero8 = w->J3 <= XLD - 8;   // 51 real inputs: k = 56..63 are zero in xpad and in the padded weight
     a.bias = tb; a.gamma = w->gamma[0]; a.beta = w->beta[0]; a.out = h; a.ldo = HID;
-    a.out_planes = f16 ? 1 : 0;
     hipError_t e;
-    { ProfScope ps(ZEDO_PROF_PRE, st); e = launch_layer(a, EPI_GN_SILU, st); }
-    a.kzero8 = 0; a.out_planes = 0;
+    const size_t per16 = (size_t)HID * HID * 2;
+    if (f16) {
+        Layer16Args b{};
+        b.K = XLD; b.N = HID; b.Mp = Bp; b.Xf32 = xpad; b.W = w->d_W16 + 4 * per16; b.unscale = w->unscale[4];
+        b.bias = tb; b.gamma = w->gamma[0]; b.beta = w->beta[0]; b.out = h; b.out_f32 = 0;
+        ProfScope ps(ZEDO_PROF_PRE, st);
+        e = launch_layer16(b, EPI_GN_SILU, st);
+    } else {
+        ProfScope ps(ZEDO_PROF_PRE, st);
+        e = launch_layer(a, EPI_GN_SILU, st);
+    }
+    a.kzero8 = 0;
     for (int blk = 0; blk < 2 && e == hipSuccess; ++blk) {
         const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
         if (f16) {
             // the same two layers: X, W and the activations between them as split-fp16 planes; the block's last layer adds
-            // the residual from h's planes and writes planes again (block 1) or fp32 for post_dense (block 2), in place
+            // the residual from h's planes and writes planes again, in place
             const size_t per = (size_t)HID * HID * 2;
             Layer16Args b{};
             b.K = HID; b.N = HID; b.Mp = Bp;
@@ -431,7 +445,7 @@ static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad
             if (e != hipSuccess) break;
             b.X = reinterpret_cast<const uint16_t *>(h1); b.W = w->d_W16 + (size_t)(l2 - 1) * per; b.unscale = w->unscale[l2 - 1];
             b.bias = tb + (size_t)l2 * HID; b.gamma = w->gamma[l2]; b.beta = w->beta[l2];
-            b.res = reinterpret_cast<const uint16_t *>(h); b.out = h; b.out_f32 = (blk == 1) ? 1 : 0;
+            b.res = reinterpret_cast<const uint16_t *>(h); b.out = h; b.out_f32 = 0;
             { ProfScope ps(ZEDO_PROF_HIDDEN, st); b.clk = ps.clk; e = launch_layer16(b, EPI_GN_SILU_RES, st); b.clk = nullptr; }
             continue;
         }
@@ -444,6 +458,19 @@ static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad
         { ProfScope ps(ZEDO_PROF_HIDDEN, st); a.clk = ps.clk; e = launch_layer(a, EPI_GN_SILU_RES, st); a.clk = nullptr; }
     }
     if (e != hipSuccess) return e;
+    if (f16) {
+        Layer16Args b{};
+        b.K = HID; b.N = XLD; b.Mp = Bp; b.X = reinterpret_cast<const uint16_t *>(h);
+        b.W = w->d_W16 + 4 * per16 + (size_t)HID * XLD * 2; b.unscale = w->unscale[5]; b.bias = w->b_post;
+        ProfScope ps(ZEDO_PROF_POST, st);
+        if (sde) {
+            b.xio = xpad; b.sde_a = sa; b.sde_c = sc;
+            b.rp_geom = nr.geom; b.rp_T = nr.T; b.rp_solve = nr.solve; b.rp_B = nr.B; b.rp_N = nr.N; b.rp_row0 = nr.row0;
+            return launch_layer16(b, EPI_SDE, st);
+        }
+        b.out = eps_out;
+        return launch_layer16(b, EPI_BIAS, st);
+    }
     a.X = h; a.ldx = HID; a.W = w->W_post; a.ldw = HID; a.K = HID; a.N = XLD; a.bias = w->b_post;
     a.gamma = a.beta = nullptr; a.ldo = XLD;
     ProfScope ps(ZEDO_PROF_POST, st);

@@ -384,28 +384,6 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
                     __syncthreads();
                 }
             }
-            if constexpr ((EPI == EPI_GN_SILU) && CPRW % 2 == 0 && (SR * CPRW / 2) % NT == 0) {
-                if (a.out_planes) {
-                    // split-fp16 planes output (zedo_tile.h): one thread = 8 consecutive channels = one 16-byte store of h
-                    // pieces and one of l pieces; the row keeps its 4 N bytes
-                    char *pbase = reinterpret_cast<char *>(a.out) + (size_t)m0 * a.ldo * 4u;
-#pragma unroll
-                    for (int pass = 0; pass < SR * CPRW / 2 / NT; ++pass) {
-                        const int qi = pass * NT + tid;
-                        const int sr = qi / (CPRW / 2), c = (qi % (CPRW / 2)) * 2;
-                        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(S + sr * BN + ((c ^ (sr & 7)) << 2));
-                        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(S + sr * BN + (((c + 1) ^ (sr & 7)) << 2));
-                        f16x8 h, l;
-                        split_f16x8(v0, v1, h, l);
-                        const int grow = (sr >> 5) * TM + j * 32 + (sr & 31), col = n0 + c * 4;
-                        const unsigned off = (unsigned)grow * (unsigned)a.ldo * 4u + (unsigned)((col >> 4) * 64 + ((col >> 3) & 1) * 16);
-                        *reinterpret_cast<f16x8 *>(pbase + off) = h;
-                        *reinterpret_cast<f16x8 *>(pbase + off + 32) = l;
-                    }
-                    if (j + 1 < TJ) __syncthreads();
-                    continue;
-                }
-            }
 #pragma unroll
             for (int pass = 0; pass < SR * CPRW / NT; ++pass) {
                 const int qi = pass * NT + tid;

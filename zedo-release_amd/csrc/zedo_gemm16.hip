@@ -57,8 +57,14 @@ hipError_t launch_split_planes(const float *src, int rows, int cols, int ld, flo
     return hipGetLastError();
 }
 
-// One BM x BN output tile.  WM x WN waves, each TM x TN = (BM/WM) x (BN/WN); ring of two 16-k blocks.
-template <int BM, int BN, int WM, int WN, int EPI>
+// One BM x BN output tile.  WM x WN waves, each TM x TN = (BM/WM) x (BN/WN); ring of NBUF 16-k blocks (2 for the big tile,
+// whose co-resident workgroups cover each other's DMA latency; 4 for the small tiles, which run at the end of a launch
+// or in small batches with the CU to themselves: a block's MFMAs (6 x 32 cycles) are far shorter than the DMA latency).
+// XF32 (pre_dense: K = 64 = NBUF blocks, everything resident): X arrives as fp32 rows [Mp][64] (the padded pose state) and is
+// split into the LDS slots by the workgroup itself - 32 values per thread, once - instead of by LDS-DMA.
+// EPI_SDE / EPI_BIAS (post_dense: BN = 64 = the padded pose row): the epilogue of zedo_gemm.hip's post_dense - bias, the SDE
+// update x' = a x + c eps on the fp32 pose state, the next iteration's reprojection correction on the rows in the LDS.
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF, int XF32 = 0>
 __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0, const int n0) {
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int TM = BM / WM, TN = BN / WN, TJ = TM / 32, TI = TN / 32;
@@ -67,7 +73,8 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     static_assert(TM % 32 == 0 && TN % 32 == 0 && IA >= 1 && IB >= 1 && (BN * CPR) % (64 * NW) == 0 && (BM * CPR) % (64 * NW) == 0, "tile");
     constexpr int SLOT = (BN + BM) * RB;                              // one ring slot: [BN rows of W][BM rows of X]
     constexpr int SR = WM * 32;                                       // epilogue stage rows per phase
-    constexpr int RING_B = 2 * SLOT, STAGE_B = SR * BN * 4, BODY_B = RING_B > STAGE_B ? RING_B : STAGE_B;
+    static_assert(NBUF >= 2 && NBUF % 2 == 0 && (NBUF - 1) * IPW <= 63, "ring depth (fragment set = slot & 1; 6-bit vmcnt)");
+    constexpr int RING_B = NBUF * SLOT, STAGE_B = SR * BN * 4, BODY_B = RING_B > STAGE_B ? RING_B : STAGE_B;
 
     extern __shared__ __attribute__((aligned(16))) char smem16[];
     float *Ps = reinterpret_cast<float *>(smem16 + BODY_B);           // [3][BN] bias | gamma | beta
@@ -91,8 +98,10 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
         const char *wk = Wbase + (size_t)kb * RB, *xk = Xbase + (size_t)kb * RB;
 #pragma unroll
         for (int p = 0; p < IA; ++p) dma16(wk, woff[p], lds0 + slot * SLOT + (wid * IA + p) * 1024);
+        if constexpr (!XF32) {
 #pragma unroll
-        for (int p = 0; p < IB; ++p) dma16(xk, xoff[p], lds0 + slot * SLOT + BN * RB + (wid * IB + p) * 1024);
+            for (int p = 0; p < IB; ++p) dma16(xk, xoff[p], lds0 + slot * SLOT + BN * RB + (wid * IB + p) * 1024);
+        }
     };
 
     f32x16 acc[TI][TJ];
@@ -136,31 +145,51 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
             for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][0], fb[set][j][0], acc[i][j], 0, 0, 0);
     };
 
+    constexpr bool GN = (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES);
     if (tid < BN / 4) {       // epilogue parameters -> LDS once
         *reinterpret_cast<f32x4 *>(Ps + tid * 4) = *reinterpret_cast<const f32x4 *>(a.bias + n0 + tid * 4);
-        *reinterpret_cast<f32x4 *>(Ps + BN + tid * 4) = *reinterpret_cast<const f32x4 *>(a.gamma + n0 + tid * 4);
-        *reinterpret_cast<f32x4 *>(Ps + 2 * BN + tid * 4) = *reinterpret_cast<const f32x4 *>(a.beta + n0 + tid * 4);
+        if constexpr (GN) {
+            *reinterpret_cast<f32x4 *>(Ps + BN + tid * 4) = *reinterpret_cast<const f32x4 *>(a.gamma + n0 + tid * 4);
+            *reinterpret_cast<f32x4 *>(Ps + 2 * BN + tid * 4) = *reinterpret_cast<const f32x4 *>(a.beta + n0 + tid * 4);
+        }
     }
-    const int KB = a.K / 16;                       // even (checked at launch): the ring slot is a compile-time constant
-    dma(0, 0);
-    dma(1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");      // block 0 landed
+    const int KB = a.K / 16;                       // multiple of NBUF (checked at launch): the ring slot is a compile-time constant
+#pragma unroll
+    for (int t = 0; t < NBUF; ++t) dma(min(t, KB - 1), t);
+    if constexpr (XF32) {
+        // the fp32 pose rows of this tile -> fp16 pieces in the X part of the NBUF (= K / 16) slots: 8 consecutive k per item
+        // = one 16-byte chunk of the h plane and one of the l plane
+        static_assert(NBUF == 4, "XF32: K = 64 resident");
+        for (int q = tid; q < BM * 8; q += NT) {
+            const int r = q >> 3, c8 = q & 7;
+            const float *src = a.Xf32 + (size_t)(m0 + r) * XLD + c8 * 8;
+            f16x8 h, l;
+            split_f16x8(*reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4), h, l);
+            char *dst = smem16 + (c8 >> 1) * SLOT + BN * RB + r * RB;
+            const int sw = (r >> 2) & 3, kh8 = c8 & 1;
+            *reinterpret_cast<f16x8 *>(dst + ((kh8 ^ sw) * 16)) = h;
+            *reinterpret_cast<f16x8 *>(dst + (((2 + kh8) ^ sw) * 16)) = l;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * IPW) : "memory");      // block 0 landed
+    }
     __syncthreads();
     fread(0, 0);
-    //   block kb in slot kb & 1, its fragments in set kb & 1:
-    //       vmcnt(0); barrier      <- every wave has read block kb (its fragments are in registers), block kb+1 has landed
-    //       DMA(block kb+2 -> slot of kb);  read(block kb+1) -> the other set;  MFMA(block kb)
-    for (int kb0 = 0; kb0 < KB; kb0 += 2) {
+    //   block kb in slot kb % NBUF, its fragments in set kb & 1:
+    //       vmcnt((NBUF-2) blocks); barrier   <- every wave has read block kb (its fragments are in registers), block kb+1 has landed
+    //       DMA(block kb+NBUF -> slot of kb);  read(block kb+1) -> the other set;  MFMA(block kb)
+    for (int kb0 = 0; kb0 < KB; kb0 += NBUF) {
 #pragma unroll
-        for (int slot = 0; slot < 2; ++slot) {
+        for (int slot = 0; slot < NBUF; ++slot) {
             const int kb = kb0 + slot;
             // hipcc does not count the LDS-DMA in its vmcnt bookkeeping: wait explicitly
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
             __syncthreads();
-            dma(min(kb + 2, KB - 1), slot);        // branch-free: past the end it refills a slot nobody reads again
-            fread(slot ^ 1, slot ^ 1);
+            if constexpr (!XF32) dma(min(kb + NBUF, KB - 1), slot);     // branch-free: past the end it refills a slot nobody reads again
+            fread((slot & 1) ^ 1, (slot + 1) % NBUF);
             __builtin_amdgcn_sched_barrier(0);
-            mma(slot);
+            mma(slot & 1);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -170,7 +199,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     // ---- epilogue: GroupNorm + SiLU on the accumulators, staged through the LDS row-wise (chunk c of stage row sr at
     //      position c ^ (sr & 7), as in zedo_gemm.hip), then per thread 16 consecutive channels of a row: [residual from
     //      its planes +] either 64 bytes of fp32 or 32 + 32 bytes of fp16 pieces - the same 64 bytes of the row either way
-    {
+    if constexpr (GN) {
         constexpr int CG = BN / 16;              // 16-channel groups per stage row
         static_assert((SR * CG) % NT == 0 || NT % (SR * CG) == 0, "write-out shape");
         float *S = reinterpret_cast<float *>(smem16);
@@ -231,37 +260,142 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
             if (j + 1 < TJ) __syncthreads();
         }
     }
+    else {
+        // ---- post_dense: out = acc * unscale + bias [, x' = a x + c out, next reprojection] on the fp32 pose rows [Mp][64]
+        static_assert(BN == XLD, "post_dense tile: one column tile of 64 (= padded pose row)");
+        constexpr int CPRW = BN / 4;             // 16-byte chunks per stage row
+        float *S = reinterpret_cast<float *>(smem16);
+        float *xbase = a.xio + (size_t)m0 * XLD;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const float *pc = Ps + wn * TN + i * 32 + 4 * kh;
+                float *srow = S + (wm * 32 + li) * BN;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b = *reinterpret_cast<const f32x4 *>(pc + 8 * g);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = __builtin_fmaf(acc[i][j][4 * g + e], a.unscale, b[e]);
+                        if constexpr (EPI == EPI_SDE) v[e] *= a.sde_c;
+                    }
+                    const int c = (wn * TN + i * 32 + 8 * g + 4 * kh) >> 2;
+                    *reinterpret_cast<f32x4 *>(srow + ((c ^ (li & 7)) << 2)) = v;
+                }
+            }
+            __syncthreads();
+            if constexpr (EPI == EPI_SDE) {
+                // x' = a x + [c eps]: one fma per element, x read row-wise (coalesced) from the pose state
+                for (int qi = tid; qi < SR * CPRW; qi += NT) {
+                    const int sr = qi / CPRW, c = qi % CPRW;
+                    const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
+                    const f32x4 x = *reinterpret_cast<const f32x4 *>(xbase + (size_t)grow * XLD + c * 4);
+                    f32x4 *slot = reinterpret_cast<f32x4 *>(S + sr * BN + ((c ^ (sr & 7)) << 2));
+                    f32x4 v = *slot;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(a.sde_a, x[e], v[e]);
+                    *slot = v;
+                }
+                __syncthreads();
+                // reprojection correction of the next iteration on the updated rows, one lane per row, straight from the
+                // stage; same source (reproj_row) as the exact-fp32 path and the stand-alone kernel
+                if (a.rp_geom != nullptr) {
+                    constexpr int NV = (17 * 3 + 3) / 4;
+                    if (tid < SR) {
+                        const int sr = tid;
+                        const int b = m0 + (sr >> 5) * TM + j * 32 + (sr & 31);
+                        if (b < a.rp_B) {
+                            float xr[NV * 4], gr[17 * 3], Tr[3];
+                            float *srow = S + sr * BN;
+#pragma unroll
+                            for (int v = 0; v < NV; ++v) {
+                                const f32x4 t = *reinterpret_cast<const f32x4 *>(srow + ((v ^ (sr & 7)) << 2));
+                                xr[4 * v] = t[0]; xr[4 * v + 1] = t[1]; xr[4 * v + 2] = t[2]; xr[4 * v + 3] = t[3];
+                            }
+                            Tr[0] = a.rp_T[(size_t)b * 3]; Tr[1] = a.rp_T[(size_t)b * 3 + 1]; Tr[2] = a.rp_T[(size_t)b * 3 + 2];
+                            const int n = (int)((a.rp_row0 + b) % a.rp_N);
+                            reproj_row<17>(xr, a.rp_geom + (size_t)n * 17 * GEOM_F, Tr, a.rp_solve != 0, gr);
+                            if (a.rp_solve) { a.rp_T[(size_t)b * 3] = Tr[0]; a.rp_T[(size_t)b * 3 + 1] = Tr[1]; a.rp_T[(size_t)b * 3 + 2] = Tr[2]; }
+#pragma unroll
+                            for (int c = 0; c < 17 * 3; ++c) xr[c] += gr[c];
+#pragma unroll
+                            for (int v = 0; v < NV; ++v) {
+                                const f32x4 t = {xr[4 * v], xr[4 * v + 1], xr[4 * v + 2], xr[4 * v + 3]};
+                                *reinterpret_cast<f32x4 *>(srow + ((v ^ (sr & 7)) << 2)) = t;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            float *obase = (EPI == EPI_SDE ? a.xio : reinterpret_cast<float *>(a.out)) + (size_t)m0 * XLD;
+            for (int qi = tid; qi < SR * CPRW; qi += NT) {
+                const int sr = qi / CPRW, c = qi % CPRW;
+                const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
+                *reinterpret_cast<f32x4 *>(obase + (size_t)grow * XLD + c * 4) = *reinterpret_cast<const f32x4 *>(S + sr * BN + ((c ^ (sr & 7)) << 2));
+            }
+            if (j + 1 < TJ) __syncthreads();
+        }
+    }
 }
 
 // block -> tile, XCD aware (the hardware places block b on XCD b % 8): every XCD gets a contiguous range of tiles so that
 // the column tiles of one row tile share one L2 (same map as zedo_gemm.hip)
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF, int XF32 = 0>
 __device__ __forceinline__ void layer16_body(const Layer16Args &a, const int bid, const int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int ncol = a.N / BN;
-    layer16_tile<BM, BN, WM, WN, EPI>(a, (lid / ncol) * BM, (lid % ncol) * BN);
+    layer16_tile<BM, BN, WM, WN, EPI, NBUF, XF32>(a, (lid / ncol) * BM, (lid % ncol) * BN);
 }
 
 // One launch, two tile shapes (as layer_pair_kernel of zedo_gemm.hip): workgroups [0, nbig) run 128x128 tiles on the rows
 // that fill whole rounds of the chip, the rest 64x128 tiles on the remainder rows, which back-fill CUs as the big tiles
-// drain.  Either count may be zero.  Three workgroups per CU (35 KB of LDS, <= 168 registers).
+// drain.  Either count may be zero.  Three workgroups per CU (49.5 KB of LDS, <= 168 registers).
 template <int EPI>
 __global__ __launch_bounds__(256, 3) void layer16_pair_kernel(Layer16Args big, Layer16Args small, int nbig) {
     long long c0 = 0, w0 = 0;
     const bool probe = big.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     if (probe) { c0 = clock64(); w0 = wall_clock64(); }
-    if ((int)blockIdx.x < nbig) layer16_body<128, 128, 2, 2, EPI>(big, blockIdx.x, nbig);
-    else layer16_body<64, 128, 2, 2, EPI>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+    if ((int)blockIdx.x < nbig) layer16_body<128, 128, 2, 2, EPI, 2>(big, blockIdx.x, nbig);
+    else layer16_body<64, 128, 2, 2, EPI, 4>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     if (probe) { big.clk[0] = clock64() - c0; big.clk[1] = wall_clock64() - w0; }
+}
+
+// The thin layers: pre_dense (51 -> 1024: 64x128 tiles, the four k blocks resident, X split from the fp32 pose state) and
+// post_dense (1024 -> 51: 64x64 tiles on a 4-deep ring, SDE / bias epilogue on the fp32 pose state).
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void layer16_pre_kernel(Layer16Args a) {
+    layer16_body<64, 128, 2, 2, EPI, 4, 1>(a, blockIdx.x, gridDim.x);
+}
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void layer16_post_kernel(Layer16Args a) {   // 2: the fused reprojection keeps ~180 values per lane live (184 registers in zedo_gemm.hip too); no scratch
+    layer16_body<64, 64, 2, 2, EPI, 4, 0>(a, blockIdx.x, gridDim.x);
 }
 
 constexpr int MAX_DEVICES16 = 16;
 
+template <class K>
+static hipError_t launch_thin16(K kern, std::atomic<bool> *attr_done, size_t lds, int grid, const Layer16Args &a, hipStream_t st) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= MAX_DEVICES16) dev = 0;
+    if (!attr_done[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
 template <int EPI>
 static hipError_t launch_pair16(const Layer16Args &big, const Layer16Args &small, hipStream_t st) {
-    constexpr size_t ring_big = 2 * (128 + 128) * 64, stage = (size_t)64 * 128 * 4;
-    constexpr size_t lds = (ring_big > stage ? ring_big : stage) + 3 * 128 * sizeof(float);
+    constexpr size_t ring_big = 2 * (128 + 128) * 64, ring_small = 4 * (128 + 64) * 64, stage = (size_t)64 * 128 * 4;
+    constexpr size_t body = ring_big > ring_small ? (ring_big > stage ? ring_big : stage) : (ring_small > stage ? ring_small : stage);
+    constexpr size_t lds = body + 3 * 128 * sizeof(float);      // the larger body; each tile shape finds its parameter block behind ITS body
     auto kern = layer16_pair_kernel<EPI>;
     static std::atomic<bool> attr_done[MAX_DEVICES16];
     int dev = 0;
@@ -288,7 +422,27 @@ static Layer16Args rows_of16(const Layer16Args &a, int row0, int rows) {
 }
 
 hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st) {
-    if (a.Mp <= 0 || a.Mp % 64 || a.N % 128 || a.K % 32 || !a.X || !a.W || !a.out) return hipErrorInvalidValue;
+    if (a.Mp <= 0 || a.Mp % 64 || a.K % 64 || !a.W) return hipErrorInvalidValue;
+    if (a.Xf32) {               // pre_dense
+        if (a.K != XLD || a.N % 128 || epilogue != EPI_GN_SILU || !a.out) return hipErrorInvalidValue;
+        static std::atomic<bool> done[MAX_DEVICES16];
+        constexpr size_t lds = (size_t)4 * (128 + 64) * 64 + 3 * 128 * sizeof(float);
+        return launch_thin16(layer16_pre_kernel<EPI_GN_SILU>, done, lds, (a.Mp / 64) * (a.N / 128), a, st);
+    }
+    if (a.N == XLD) {           // post_dense
+        if (!a.X) return hipErrorInvalidValue;
+        constexpr size_t lds = (size_t)4 * (64 + 64) * 64 + 3 * 64 * sizeof(float);
+        if (epilogue == EPI_SDE && a.xio) {
+            static std::atomic<bool> done[MAX_DEVICES16];
+            return launch_thin16(layer16_post_kernel<EPI_SDE>, done, lds, a.Mp / 64, a, st);
+        }
+        if (epilogue == EPI_BIAS && a.out) {
+            static std::atomic<bool> done[MAX_DEVICES16];
+            return launch_thin16(layer16_post_kernel<EPI_BIAS>, done, lds, a.Mp / 64, a, st);
+        }
+        return hipErrorInvalidValue;
+    }
+    if (a.N % 128 || !a.X || !a.out) return hipErrorInvalidValue;
     if (epilogue == EPI_GN_SILU_RES && !a.res) return hipErrorInvalidValue;
     static std::atomic<int> cus_cached{0};
     int cus = cus_cached.load(std::memory_order_relaxed);

@@ -34,7 +34,6 @@ struct LayerArgs {
     int N;               // multiple of the tile's BN
     int Mp;              // multiple of the tile's BM
     float sde_a, sde_c;  // EPI_SDE
-    int out_planes;      // GN epilogues with N % 16 == 0: write the output in the split-fp16 planes format (zedo_tile.h) instead of fp32
     int kzero8;          // K == 64 only: columns k = 56..63 of X and W are zero padding (their MFMAs are skipped)
     long long *clk;      // diagnostic (may be null): workgroup 0 writes {shader cycles, 100 MHz wall ticks} it spent in the tile
     // EPI_SDE only, optional (rp_geom != nullptr): the reprojection correction of the NEXT loop iteration
@@ -58,8 +57,18 @@ struct Layer16Args {
     const uint16_t *res;    // EPI_GN_SILU_RES: residual planes [Mp][N/16][2][16]; may be the output buffer (in place)
     void *out;              // planes [Mp][N/16][2][16] (out_f32 == 0) or fp32 [Mp][N] (out_f32 != 0): the same 4 N bytes per row
     int out_f32;
-    int K, N, Mp;           // K % 32 == 0, N % 128 == 0, Mp % 64 == 0
+    int K, N, Mp;           // K % 64 == 0, N % 128 == 0 (or N == 64: post_dense), Mp % 64 == 0
     long long *clk;         // diagnostic (may be null), as in LayerArgs
+    // pre_dense (K == 64): X == nullptr and the operand is the fp32 pose state itself, split by the kernel
+    const float *Xf32;      // [Mp][64]
+    // post_dense (N == 64, EPI_SDE / EPI_BIAS): fp32 pose state updated in place (EPI_SDE) or eps written to `out` as fp32
+    // [Mp][64] (EPI_BIAS); the optional fused reprojection of the next iteration as in LayerArgs
+    float *xio;             // [Mp][64]
+    float sde_a, sde_c;
+    const float *rp_geom;
+    float *rp_T;
+    int rp_solve, rp_B, rp_N;
+    long long rp_row0;
 };
 hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st);
 // fp32 [rows][cols] (row stride ld floats) * scale -> planes [rows][cols/16][2][16]; cols % 16 == 0
