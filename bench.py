@@ -143,9 +143,9 @@ def roofline_f16x3(h2, rows_launch):
     sustains (the binding resource)."""
     issued = 3 * 2.0 * rows_launch * 1024 * 1024
     ghz = h2.get("shader_clock_ghz") or 0.0
-    dma_bytes = (rows_launch / 128.0) * 8 * 64 * (128 + 128) * 64      # row tiles x column tiles x k blocks x 16 KB
+    dma_bytes = (rows_launch / 128.0) * 4 * 64 * (128 + 256) * 64      # row tiles x column tiles x k blocks x 24 KB (128 x 256 tiles)
     t = h2["avg_ms"] * 1e-3
-    return dict(bound="mfma", kernel="zedo::layer16_pair_kernel (128x128 tiles, split-fp16 operands, 3 x v_mfma_f32_32x32x16_f16 per 16-k block)",
+    return dict(bound="mfma", kernel="zedo::layer16_pair_kernel (128x256 tiles + 64x128 remainder tiles, split-fp16 operands, 3 x v_mfma_f32_32x32x16_f16 per 16-k block)",
                 achieved=round(issued / t / 1e12, 1), peak=2500.0, unit="TFLOP/s", frac=round(issued / t / 1e12 / 2500.0, 4),
                 traffic=None, fp32_equivalent_tflops=round(2.0 * rows_launch * 1024 * 1024 / t / 1e12, 1),
                 avg_launch_ms=round(h2["avg_ms"], 4), sampled_launches=h2["samples"], launches=h2["launches"],
@@ -153,8 +153,11 @@ def roofline_f16x3(h2, rows_launch):
                 frac_at_kernel_clock=(round(issued / t / 1e12 / (2500.0 * ghz / 2.4), 4) if ghz else None),
                 lds_dma_bytes_per_launch=int(dma_bytes), lds_dma_tb_per_s=round(dma_bytes / t / 1e12, 2),
                 lds_dma_sustained_tb_per_s=(round(16.0 * 256 * ghz * 1e9 / 1e12, 2) if ghz else None),
-                note="power management holds the shader clock near 1.8 GHz under the dense fp16 MFMA stream; operands cross "
-                     "L2 -> LDS at 4 B per element and LDS-DMA sustains ~16 B/clk/CU (tools/ubench/ubench_f16x3.hip)")
+                vmem_model_ms=round(((rows_launch / 32) * 32 * 64 * 3 * 32 + dma_bytes / 1024 * 65 + rows_launch * 4096 / 1024 * 187)
+                                    / 1024 / (ghz * 1e9) * 1e3, 4) if ghz else None,
+                note="power management holds the shader clock near 1.8 GHz under the dense fp16 MFMA stream; on this pipe a SIMD's "
+                     "vector-memory instructions serialise with its MFMAs (65 cycles per 1 KB LDS-DMA, 187 per 1 KB store, "
+                     "profiles/coissue_f16_r03.txt): vmem_model_ms = (MFMA + LDS-DMA + store cycles) / 1024 SIMDs at the kernel's clock")
 
 
 def selection_digest(out):

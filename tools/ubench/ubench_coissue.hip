@@ -6,6 +6,10 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#ifndef MFMA_F16
+#define MFMA_F16 0      // 1: the MFMA stream is v_mfma_f32_32x32x16_f16 (32 cycles each) instead of v_mfma_f32_32x32x2_f32 (64)
+#endif
 
 template <int KIND>
 __global__ __launch_bounds__(512) void k(float *out, const float *gin, int nm, int nf, int with_mfma) {
@@ -20,7 +24,14 @@ __global__ __launch_bounds__(512) void k(float *out, const float *gin, int nm, i
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+#if MFMA_F16
+                    f16x8 ha, hb; for (int e = 0; e < 8; ++e) { ha[e] = (_Float16)a; hb[e] = (_Float16)b; }
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, acc[i], 0, 0, 0);
+#else
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+#endif
+                }
         }
         float s = 0; for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
         out[blockIdx.x * 512 + threadIdx.x] = s;
@@ -56,10 +67,12 @@ __global__ __launch_bounds__(512) void k(float *out, const float *gin, int nm, i
                 else if constexpr (KIND == 13) {   // one 16-byte load per 16 slots (low VMEM rate)
                     if (u == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(gp)); else asm volatile("s_nop 7");
                 }
+                else if constexpr (KIND == 15) { asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(gp), "v"(v) : "memory"); }
+                else if constexpr (KIND == 16) { asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(x0)); }
                 else if constexpr (KIND == 14) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(*(double*)&v) : "v"(gp)); }
             }
             if constexpr (KIND == 2 || KIND == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (KIND == 4 || KIND == 10 || KIND == 11 || KIND == 13 || KIND == 14) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (KIND == 4 || KIND == 10 || KIND == 11 || KIND == 13 || KIND == 14 || KIND == 15) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         out[blockIdx.x * 512 + threadIdx.x] = x0 + v[0] + v[1];
     }
@@ -85,8 +98,13 @@ template <int KIND> int run(const char *name, float *out, float *gin) {
     return 0;
 }
 int main() {
+    printf("MFMA stream: %s\n", MFMA_F16 ? "v_mfma_f32_32x32x16_f16" : "v_mfma_f32_32x32x2_f32");
     float *out, *gin; CK(hipMalloc(&out, 1 << 22)); CK(hipMalloc(&gin, 1 << 22)); CK(hipMemset(gin, 0, 1 << 22));
     run<12>("v_fma_f32 x4 indep", out, gin);
+#if MFMA_F16
+    run<0>("v_fma_f32 dependent", out, gin); run<1>("v_exp_f32", out, gin); run<9>("v_rcp_f32", out, gin); run<8>("v_pk_fma_f32", out, gin);
+    run<16>("v_cvt_f16_f32", out, gin); run<2>("ds_read_b128", out, gin); run<3>("ds_write_b128", out, gin); run<15>("global_store_dwordx4", out, gin);
+#endif
     run<4>("global_load_dwordx4", out, gin); run<14>("global_load_dwordx2", out, gin); run<11>("global_load_dword", out, gin);
     run<10>("global_load_lds_dwordx4", out, gin); run<13>("1 dwordx4 per 16 slots", out, gin);
     return 0;

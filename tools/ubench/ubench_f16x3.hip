@@ -32,6 +32,7 @@ struct Args {
     int M, N, K;
     float unscale;        // 2^-wshift
     long long *clk;       // {shader cycles, 100 MHz ticks} of workgroup 0
+    int stagger;          // experiment: first-round workgroups of CU slot s start s * stagger x 8128 cycles late
 };
 
 __device__ __forceinline__ void dma16(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
@@ -61,6 +62,10 @@ __global__ __launch_bounds__(WM *WN * 64, WPE) void hf_kernel(Args a) {
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int ncol = a.N / BN;
     const int m0 = (lid / ncol) * BM, n0 = (lid % ncol) * BN;
+    if (a.stagger > 0) {
+        const int q = bid >> 3;                          // index inside the XCD: the first 32 land on 32 CUs, the next 32 on their second slots, ...
+        if (q < 32 * WPE) { const int slot = q / 32; for (int t = 0; t < slot * a.stagger; ++t) __builtin_amdgcn_s_sleep(127); }
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN, li = lane & 31, kh = lane >> 5;
@@ -295,6 +300,7 @@ int main(int argc, char **argv) {
     a.X2 = dx; a.W2 = dw; a.bias = db; a.gamma = dg; a.beta = dbe; a.out = dy; a.M = M; a.N = N; a.K = K; a.unscale = 1.0f / wscale;
     //    BM   BN  WM WN NBUF NODMA WPE KPS      NODMA bits: 1 no in-loop DMA, 2 no in-loop LDS reads, 4 no in-loop barrier
     const int only = argc > 3 ? atoi(argv[3]) : -1;
+    a.stagger = argc > 4 ? atoi(argv[4]) : 0;
     int v = 0;
 #define RUN(NAME, ...) { if (only < 0 || only == v) run<__VA_ARGS__>(NAME, a, rows, cref); ++v; }
     RUN("128x128 4w ring2 k16 lb3", 128, 128, 2, 2, 2, 0, 3, 1)
@@ -311,5 +317,11 @@ int main(int argc, char **argv) {
     RUN("256x256 8w(64x128) ring4 k16", 256, 256, 4, 2, 4, 0, 1, 1)
     RUN("256x128 8w(64x64) ring2 k32 lb2", 256, 128, 4, 2, 2, 0, 2, 2)
     RUN("256x128 8w(64x64) ring2 k16 lb3", 256, 128, 4, 2, 2, 0, 3, 1)
+    RUN("128x256 4w(64x128) ring2 k16 lb2", 128, 256, 2, 2, 2, 0, 2, 1)
+    RUN("256x128 4w(128x64) ring2 k16 lb2", 256, 128, 2, 2, 2, 0, 2, 1)
+    RUN("128x256 4w(64x128) ring2 k32 lb2", 128, 256, 2, 2, 2, 0, 2, 2)
+    RUN("128x256 4w(64x128) ring4 k16 lb2", 128, 256, 2, 2, 4, 0, 2, 1)
+    RUN("128x256 4w(64x128) k16 lb2 no DMA", 128, 256, 2, 2, 2, 1, 2, 1)
+    RUN("256x256 8w(64x128) ring2 k16 lb2 again", 256, 256, 4, 2, 2, 0, 2, 1)
     return 0;
 }

@@ -218,7 +218,9 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
                     ga[g] = *reinterpret_cast<const f32x4 *>(pc + BN + 8 * g);
                     be[g] = *reinterpret_cast<const f32x4 *>(pc + 2 * BN + 8 * g);
                 }
-                epilogue_values<EPI_GN_SILU, true>(acc[i][j], b4, ga, be, 0.f, o, a.unscale);
+                // hidden layers: scalar VALU (free beside the other workgroups' fp16 MFMAs); pre_dense has 12 MFMAs per tile and is
+                // bound by this very arithmetic: packed fp32 halves its instruction count
+                epilogue_values<EPI_GN_SILU, true, XF32 != 0>(acc[i][j], b4, ga, be, 0.f, o, a.unscale);
                 float *srow = S + (wm * 32 + li) * BN;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -351,15 +353,22 @@ __device__ __forceinline__ void layer16_body(const Layer16Args &a, const int bid
     layer16_tile<BM, BN, WM, WN, EPI, NBUF, XF32>(a, (lid / ncol) * BM, (lid % ncol) * BN);
 }
 
-// One launch, two tile shapes (as layer_pair_kernel of zedo_gemm.hip): workgroups [0, nbig) run 128x128 tiles on the rows
+// One launch, two tile shapes (as layer_pair_kernel of zedo_gemm.hip): workgroups [0, nbig) run BIG_M x BIG_N tiles on the rows
 // that fill whole rounds of the chip, the rest 64x128 tiles on the remainder rows, which back-fill CUs as the big tiles
-// drain.  Either count may be zero.  Three workgroups per CU (49.5 KB of LDS, <= 168 registers).
+// drain.  Either count may be zero.
+// The big tile is 128 rows x 256 channels (four waves of 64 x 128, 230 registers, two workgroups per CU, 67 KB of LDS): on this
+// pipe every vector-memory instruction of a SIMD - LDS-DMA, load, store - serialises with its MFMAs at full price (65 cycles
+// per 1 KB LDS-DMA, 187 per 1 KB store; plain VALU is free; profiles/coissue_f16_r03.txt), so the layer's time is MFMA cycles +
+// VMEM cycles, and the tile shape sets the VMEM share: LDS-DMA cycles / MFMA cycles = 43 (BM + BN) / (BM BN) = 0.68 for
+// 128x128, 0.51 for 128x256 (measured 341 -> 313 us per layer, profiles/ubench_f16x3_tiles_r03.txt), 0.34 for 256x256
+// (291 us, eight waves, one workgroup per CU: not adopted).
+constexpr int BIG_M = 128, BIG_N = 256;
 template <int EPI>
-__global__ __launch_bounds__(256, 3) void layer16_pair_kernel(Layer16Args big, Layer16Args small, int nbig) {
+__global__ __launch_bounds__(256, 2) void layer16_pair_kernel(Layer16Args big, Layer16Args small, int nbig) {
     long long c0 = 0, w0 = 0;
     const bool probe = big.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     if (probe) { c0 = clock64(); w0 = wall_clock64(); }
-    if ((int)blockIdx.x < nbig) layer16_body<128, 128, 2, 2, EPI, 2>(big, blockIdx.x, nbig);
+    if ((int)blockIdx.x < nbig) layer16_body<BIG_M, BIG_N, 2, 2, EPI, 2>(big, blockIdx.x, nbig);
     else layer16_body<64, 128, 2, 2, EPI, 4>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     if (probe) { big.clk[0] = clock64() - c0; big.clk[1] = wall_clock64() - w0; }
 }
@@ -393,9 +402,11 @@ static hipError_t launch_thin16(K kern, std::atomic<bool> *attr_done, size_t lds
 
 template <int EPI>
 static hipError_t launch_pair16(const Layer16Args &big, const Layer16Args &small, hipStream_t st) {
-    constexpr size_t ring_big = 2 * (128 + 128) * 64, ring_small = 4 * (128 + 64) * 64, stage = (size_t)64 * 128 * 4;
-    constexpr size_t body = ring_big > ring_small ? (ring_big > stage ? ring_big : stage) : (ring_small > stage ? ring_small : stage);
-    constexpr size_t lds = body + 3 * 128 * sizeof(float);      // the larger body; each tile shape finds its parameter block behind ITS body
+    constexpr size_t ring_big = 2 * (BIG_M + BIG_N) * 64, stage_big = (size_t)64 * BIG_N * 4, par_big = 3 * BIG_N * sizeof(float);
+    constexpr size_t ring_small = 4 * (128 + 64) * 64, stage_small = (size_t)64 * 128 * 4, par_small = 3 * 128 * sizeof(float);
+    constexpr size_t lds_big = (ring_big > stage_big ? ring_big : stage_big) + par_big;
+    constexpr size_t lds_small = (ring_small > stage_small ? ring_small : stage_small) + par_small;
+    constexpr size_t lds = lds_big > lds_small ? lds_big : lds_small;      // each tile shape finds its parameter block behind ITS body
     auto kern = layer16_pair_kernel<EPI>;
     static std::atomic<bool> attr_done[MAX_DEVICES16];
     int dev = 0;
@@ -406,7 +417,7 @@ static hipError_t launch_pair16(const Layer16Args &big, const Layer16Args &small
         if (e != hipSuccess) return e;
         attr_done[dev].store(true, std::memory_order_release);
     }
-    const int nbig = (big.Mp / 128) * (big.N / 128), nsmall = (small.Mp / 64) * (small.N / 128);
+    const int nbig = (big.Mp / BIG_M) * (big.N / BIG_N), nsmall = (small.Mp / 64) * (small.N / 128);
     if (nbig + nsmall == 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(nbig + nsmall), dim3(256), lds, st, big, small, nbig);
     return hipGetLastError();
@@ -453,9 +464,10 @@ hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st) {
         cus = (hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
         cus_cached.store(cus, std::memory_order_relaxed);
     }
-    // 128x128 tiles on the rows that fill whole rounds of 3 workgroups per CU; the remainder (and every batch smaller than
+    // big tiles on the rows that fill whole rounds of 2 workgroups per CU; the remainder (and every batch smaller than
     // one round) on 64x128 tiles: finer tiles spread a short launch over more CUs
-    const int per_round = cus * 3 * 128 / (a.N / 128);
+    if (a.N % BIG_N) return hipErrorInvalidValue;
+    const int per_round = cus * 2 * BIG_M / (a.N / BIG_N);
     const int rows_big = (a.Mp / per_round) * per_round, rows_small = a.Mp - rows_big;
     const Layer16Args big = rows_of16(a, 0, rows_big), small = rows_of16(a, rows_big, rows_small);
     switch (epilogue) {

@@ -70,9 +70,51 @@ __device__ __forceinline__ float silu_fast(float y) {
 // channel half kh), o[4g+e] belongs to channel cbase + 8g + e.  The residual / previous-x term is added by
 // the caller from the LDS stage (EPI_GN_SILU_RES: o += h;  EPI_SDE: o += sde_a * x).
 // SCALED (split-fp16 tiles, whose W operand carries a power-of-two scale): acc * acc_scale + bias in one fma.
-template <int EPI, bool SCALED = false>
+// PACKED = false (split-fp16 tiles): the same arithmetic on single floats.  Beside a co-resident wave's fp16 MFMAs a plain
+// VALU instruction issues for free while a packed-fp32 one costs ~9 matrix-pipe cycles (profiles/coissue_f16_r03.txt) - the
+// opposite of the exact-fp32 regime, where every VALU issue slot is matrix-pipe time and packing halves the slots.  The
+// results are bit-identical either way (same operations, same order; -ffp-contract=off).
+template <int EPI, bool SCALED = false, bool PACKED = true>
 __device__ __forceinline__ void epilogue_values(const f32x16 &acc, const f32x4 (&b4)[4], const f32x4 (&ga)[4],
                                                 const f32x4 (&be)[4], float sde_c, float (&o)[16], float acc_scale = 1.0f) {
+    if constexpr ((EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) && !PACKED) {
+        float p[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float b = b4[k >> 2][k & 3];
+            if constexpr (SCALED) p[k] = __builtin_fmaf(acc[k], acc_scale, b);
+            else p[k] = acc[k] + b;
+        }
+        // the same summation tree as the packed form: two lanes of pairs (even / odd elements), then their sum
+        float se = p[0], so = p[1];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { se += p[2 * k]; so += p[2 * k + 1]; }
+        float s = se + so;
+        s += __shfl_xor(s, 32);
+        const float mean = s * (1.0f / 32.0f);
+        float qe = 0.0f, qo = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            p[2 * k] -= mean; p[2 * k + 1] -= mean;
+            qe = __builtin_fmaf(p[2 * k], p[2 * k], qe);
+            qo = __builtin_fmaf(p[2 * k + 1], p[2 * k + 1], qo);
+        }
+        float qs = qe + qo;
+        qs += __shfl_xor(qs, 32);
+#ifdef ZEDO_MUT_GN_EPS
+        constexpr float GN_EPS_S = 2e-5f;
+#else
+        constexpr float GN_EPS_S = 1e-5f;
+#endif
+        const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(qs, 1.0f / 32.0f, GN_EPS_S));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float y = __builtin_fmaf(p[k], rstd * ga[k >> 2][k & 3], be[k >> 2][k & 3]);
+            const float d = __builtin_amdgcn_exp2f(y * -1.44269504088896340736f) + 1.0f;
+            o[k] = y * __builtin_amdgcn_rcpf(d);
+        }
+        return;
+    }
     if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
         // GroupNorm(32 groups of 32 channels, biased variance, eps 1e-5: model.py:116,145,150) then SiLU:
         //   o = acc + bias;  mean = sum32(o)/32;  o -= mean;  rstd = rsq(sum32(o^2)/32 + 1e-5);
