@@ -81,6 +81,11 @@ __global__ __launch_bounds__(WM *WN * 64, WPE) void hf_kernel(Args a) {
     for (int p = 0; p < IA; ++p) { const int g = (wid * IA + p) * 64 + lane; const int r_ = g / CPR, c_ = (g % CPR) ^ swz(r_); woff[p] = (unsigned)(r_ * rstride + c_ * 16); }
 #pragma unroll
     for (int p = 0; p < IB; ++p) { const int g = (wid * IB + p) * 64 + lane; const int r_ = g / CPR, c_ = (g % CPR) ^ swz(r_); xoff[p] = (unsigned)(r_ * rstride + c_ * 16); }
+    auto dma_one = [&](int st, int slot, int p) {     // DMA instruction p of a stage: W rows first, then X rows
+        const char *wk = Wbase + (size_t)st * RB, *xk = Xbase + (size_t)st * RB;
+        if (p < IA) dma16(wk, woff[p], lds0 + slot * SLOT + (wid * IA + p) * 1024);
+        else dma16(xk, xoff[p - IA], lds0 + slot * SLOT + BN * RB + (wid * IB + (p - IA)) * 1024);
+    };
     auto dma = [&](int st, int slot) {
         const char *wk = Wbase + (size_t)st * RB, *xk = Xbase + (size_t)st * RB;
 #pragma unroll
@@ -119,6 +124,23 @@ __global__ __launch_bounds__(WM *WN * 64, WPE) void hf_kernel(Args a) {
         FOR_TILES(acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][0], fb[set][j][1], acc[i][j], 0, 0, 0))   // hl
         FOR_TILES(acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][0], fb[set][j][0], acc[i][j], 0, 0, 0))   // hh
     };
+    // the same MFMAs with the DMA instructions of stage `st` (slot `slot`) spread evenly between them
+    auto mma_spread = [&](int set, int st, int slot) {
+        constexpr int NM = 3 * TI * TJ;
+        int m = 0, p = 0;
+#pragma unroll
+        for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    if (p < IPW && m * IPW >= p * NM) { dma_one(st, slot, p); ++p; __builtin_amdgcn_sched_barrier(0); }
+                    const int ap = prod == 0 ? 1 : 0, bp = prod == 1 ? 1 : 0;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][ap], fb[set][j][bp], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ++m;
+                }
+    };
     // stage st in ring slot st % NBUF.  per stage: for each 16-k block: read next block's fragments, MFMAs of this block;
     // before the last block's MFMAs: vmcnt + barrier (stage fully read by all, next stage landed), DMA of stage st+NBUF
     static_assert(NBUF >= 2, "ring");
@@ -144,11 +166,17 @@ __global__ __launch_bounds__(WM *WN * 64, WPE) void hf_kernel(Args a) {
                 } else {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
                     if (!(NODMA & 4)) __syncthreads();
+                    if constexpr ((NODMA & 8) != 0) {
+                        fread(set ^ 1, nxt, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma_spread(set, min(st + NBUF, NST - 1), slot);
+                    } else {
                     if (!(NODMA & 1)) dma(min(st + NBUF, NST - 1), slot);
                     if (!(NODMA & 2)) fread(set ^ 1, nxt, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     mma(set);
                     __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         }
@@ -318,6 +346,10 @@ int main(int argc, char **argv) {
     RUN("256x128 8w(64x64) ring2 k32 lb2", 256, 128, 4, 2, 2, 0, 2, 2)
     RUN("256x128 8w(64x64) ring2 k16 lb3", 256, 128, 4, 2, 2, 0, 3, 1)
     RUN("128x256 4w(64x128) ring2 k16 lb2", 128, 256, 2, 2, 2, 0, 2, 1)
+    RUN("128x256 4w ring2 k16 lb2 DMA spread", 128, 256, 2, 2, 2, 8, 2, 1)
+    RUN("128x128 4w ring2 k16 lb3 DMA spread", 128, 128, 2, 2, 2, 8, 3, 1)
+    RUN("256x256 8w ring2 k16 lb2 DMA spread", 256, 256, 4, 2, 2, 8, 2, 1)
+    RUN("128x256 4w ring4 k16 lb2 DMA spread", 128, 256, 2, 2, 4, 8, 2, 1)
     RUN("256x128 4w(128x64) ring2 k16 lb2", 256, 128, 2, 2, 2, 0, 2, 1)
     RUN("128x256 4w(64x128) ring2 k32 lb2", 128, 256, 2, 2, 2, 0, 2, 2)
     RUN("128x256 4w(64x128) ring4 k16 lb2", 128, 256, 2, 2, 4, 0, 2, 1)

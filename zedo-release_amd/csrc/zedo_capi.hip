@@ -345,7 +345,12 @@ extern "C" int zedo_schedule_create(const zedo_weights_t *w, const float *h_t, i
         a.out = s->d_tbias + (size_t)l * HID; a.ldo = NLAYER * HID; a.K = EMB; a.N = HID; a.Mp = Sp;
         e = launch_layer(a, EPI_BIAS, st);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);      // h_t may be freed by the caller; the scratch is released
+    // h_t may be freed by the caller and the borrowed scratch is released with the lock: nothing enqueued above may still be
+    // running then - on the error path as well (an earlier launch or the copy may be in flight when a later step failed)
+    {
+        const hipError_t es = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = es;
+    }
     if (!borrow) { (void)hipFree(d_t); (void)hipFree(d_pe); (void)hipFree(d_temb); }
     if (e != hipSuccess) { (void)hipFree(s->d_tbias); delete s; return (int)e; }
     *out = s;

@@ -670,26 +670,37 @@ hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStr
     const int blocks = num_cus() * 2;          // 2 blocks of 4 waves per CU: 2 waves per SIMD, dependent chains hidden
     float *d_out = nullptr;
     long long *d_clk = nullptr, clk[2] = {0, 0};
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.f;
     hipError_t e = hipMalloc(&d_out, (size_t)blocks * 256 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&d_clk, 16);
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, d_out, iters / 4, d_clk);   // warm the clocks
-    (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, d_out, iters, d_clk);
-    (void)hipEventRecord(e1, st);
-    e = hipEventSynchronize(e1);
-    float ms = 0.f;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, d_out, iters / 4, d_clk);   // warm the clocks
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(e0, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, d_out, iters, d_clk);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
     if (e == hipSuccess) e = hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost);
     if (e == hipSuccess) {
         const double flop = (double)blocks * 4 * iters * 16 * 2.0 * 32 * 32 * 2;
         if (tflops) *tflops = flop / ms / 1e9;
         if (shader_ghz) *shader_ghz = clk[1] > 0 ? (double)clk[0] / ((double)clk[1] / 100e6) / 1e9 : 0.0;   // wall_clock64 ticks at 100 MHz
+    } else {
+        (void)hipStreamSynchronize(st);        // nothing of this probe may still run when its buffers go away
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d_out); (void)hipFree(d_clk);
+    // one way out: whatever was created is released
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_out);
+    (void)hipFree(d_clk);
     return e;
 }
 

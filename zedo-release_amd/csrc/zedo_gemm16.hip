@@ -374,14 +374,15 @@ __global__ __launch_bounds__(256, 2) void layer16_pair_kernel(Layer16Args big, L
 }
 
 // The thin layers: pre_dense (51 -> 1024: 64x128 tiles, the four k blocks resident, X split from the fp32 pose state) and
-// post_dense (1024 -> 51: 64x64 tiles on a 4-deep ring, SDE / bias epilogue on the fp32 pose state).
+// post_dense (1024 -> 51: 64x64 tiles on an 8-deep ring - a block is 3 MFMAs per wave, 96 cycles: only a deep ring keeps the
+// DMA round trip off the critical path -, SDE / bias epilogue on the fp32 pose state).
 template <int EPI>
 __global__ __launch_bounds__(256, 3) void layer16_pre_kernel(Layer16Args a) {
     layer16_body<64, 128, 2, 2, EPI, 4, 1>(a, blockIdx.x, gridDim.x);
 }
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void layer16_post_kernel(Layer16Args a) {   // 2: the fused reprojection keeps ~180 values per lane live (184 registers in zedo_gemm.hip too); no scratch
-    layer16_body<64, 64, 2, 2, EPI, 4, 0>(a, blockIdx.x, gridDim.x);
+    layer16_body<64, 64, 2, 2, EPI, 8, 0>(a, blockIdx.x, gridDim.x);
 }
 
 constexpr int MAX_DEVICES16 = 16;
@@ -442,7 +443,7 @@ hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st) {
     }
     if (a.N == XLD) {           // post_dense
         if (!a.X) return hipErrorInvalidValue;
-        constexpr size_t lds = (size_t)4 * (64 + 64) * 64 + 3 * 64 * sizeof(float);
+        constexpr size_t lds = (size_t)8 * (64 + 64) * 64 + 3 * 64 * sizeof(float);
         if (epilogue == EPI_SDE && a.xio) {
             static std::atomic<bool> done[MAX_DEVICES16];
             return launch_thin16(layer16_post_kernel<EPI_SDE>, done, lds, a.Mp / 64, a, st);
