@@ -14,12 +14,14 @@
 // 2^14)) undone exactly in the epilogue's first fma; activations are O(1..10) and unscaled; the matrix pipe honours fp16
 // denormals (probed), so tiny pieces cost an absolute 3e-8, not a flush.
 //
-// What bounds it (MI355X, tools/ubench/ubench_f16x3.hip, profiles/ubench_f16x3_r03.txt): three fp16 MFMAs are 96 matrix-
-// pipe cycles against 512 for the eight exact-fp32 MFMAs of the same block, but (i) under a dense fp16 MFMA stream power
-// management holds the shader clock at 1.7-1.85 GHz (2.36 for the fp32 kernel): the MFMA floor of a 50k-row layer is ~165 us,
-// not 127; (ii) the operands still cross L2 -> LDS at 4 bytes per element, and LDS-DMA sustains ~16 B/clk/CU (1 KB per
-// ~65 cycles of a CU's vector-memory path, 9.6 TB/s on the chip): 128x128 tiles move 3.2 GB per layer = the 335 us this
-// shape measures, i.e. the layer is bound by LDS-DMA throughput, no longer by the matrix pipe.
+// What bounds it (MI355X; tools/ubench/ubench_f16x3.hip, ubench_coissue.hip -DMFMA_F16=1; profiles/ubench_f16x3*_r03.txt,
+// coissue_f16_r03.txt): three fp16 MFMAs are 96 matrix-pipe cycles against 512 for the eight exact-fp32 MFMAs of the same
+// block, but (i) under a dense fp16 MFMA stream power management holds the shader clock at 1.7-1.85 GHz (2.36 for the fp32
+// kernel): the MFMA floor of a 50k-row layer is ~165 us, not 127; (ii) beside an fp16 MFMA a SIMD issues plain VALU for free,
+// but every vector-memory instruction at its full stand-alone price - 65 cycles per 1 KB LDS-DMA or load, 187 per 1 KB
+// store - wherever it is placed: a layer costs MFMA cycles + VMEM cycles, and the operands still cross L2 -> LDS at 4 bytes
+// per element.  The tile shape sets that share (see layer16_pair_kernel); the epilogue is scalar fp32 (no v_pk_*: those
+// cost ~9 cycles each here, the file is built with -fno-slp-vectorize).
 //
 // Mapping, LDS layout and loop are the exact-fp32 kernel's (zedo_gemm.hip) with 64-byte LDS rows:
 //   i = output CHANNEL (rows of W, MFMA A operand), j = BATCH ROW (rows of X, B operand); lane (li, kh) holds k = 8 kh .. 8 kh + 7
