@@ -68,11 +68,15 @@ __global__ __launch_bounds__(512) void k(float *out, const float *gin, int nm, i
                     if (u == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(gp)); else asm volatile("s_nop 7");
                 }
                 else if constexpr (KIND == 15) { asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(gp), "v"(v) : "memory"); }
+                else if constexpr (KIND == 17) { asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(gp), "v"(v) : "memory"); }
+                else if constexpr (KIND == 18) { asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(gp), "v"(*(double*)&v) : "memory"); }
+                else if constexpr (KIND == 19) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(gp), "v"(v) : "memory"); }
+                else if constexpr (KIND == 20) { asm volatile("global_store_dword %0, %1, off" :: "v"(gp), "v"(x1) : "memory"); }
                 else if constexpr (KIND == 16) { asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(x0)); }
                 else if constexpr (KIND == 14) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(*(double*)&v) : "v"(gp)); }
             }
             if constexpr (KIND == 2 || KIND == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (KIND == 4 || KIND == 10 || KIND == 11 || KIND == 13 || KIND == 14 || KIND == 15) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (KIND == 4 || KIND == 10 || KIND == 11 || KIND == 13 || KIND == 14 || KIND == 15 || KIND == 17 || KIND == 18 || KIND == 19 || KIND == 20) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         out[blockIdx.x * 512 + threadIdx.x] = x0 + v[0] + v[1];
     }
@@ -104,6 +108,7 @@ int main() {
 #if MFMA_F16
     run<0>("v_fma_f32 dependent", out, gin); run<1>("v_exp_f32", out, gin); run<9>("v_rcp_f32", out, gin); run<8>("v_pk_fma_f32", out, gin);
     run<16>("v_cvt_f16_f32", out, gin); run<2>("ds_read_b128", out, gin); run<3>("ds_write_b128", out, gin); run<15>("global_store_dwordx4", out, gin);
+    run<17>("global_store_dwordx4 nt", out, gin); run<19>("global_store_dwordx4 sc0 sc1", out, gin); run<18>("global_store_dwordx2", out, gin); run<20>("global_store_dword", out, gin);
 #endif
     run<4>("global_load_dwordx4", out, gin); run<14>("global_load_dwordx2", out, gin); run<11>("global_load_dword", out, gin);
     run<10>("global_load_lds_dwordx4", out, gin); run<13>("1 dwordx4 per 16 slots", out, gin);
