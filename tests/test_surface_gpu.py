@@ -363,9 +363,11 @@ def test_fused_driver_at_baseline_size_matches_reference(weights0, golden, name)
         assert h["median"] <= 1.5 * r["median"] + 0.02 and h["p90"] <= 1.5 * r["p90"] + 0.02, (key, h, r)
 
 
-def test_run_opt_main_and_inference_synthetic(tmp_path):
+def test_run_opt_main_and_inference_synthetic(tmp_path, math_mode):
     import run.inference as inf
     import run.opt_main as om
+    # --math on the command line = the ZEDO_MATH environment variable (here: the mode this part of the suite runs in)
+    assert om.parse_args(["prog", "--config", cfg_path("pw3d"), "--math", math_mode]).math == math_mode
     a = om.parse_args(["prog", "--config", cfg_path("pw3d"), "--hypo", "3", "--synthetic", "40", "--oil_iterations", "20"])
     p1, p2 = om.main(a)
     assert np.isfinite(p1) and np.isfinite(p2) and p2 <= p1 + 1e-9

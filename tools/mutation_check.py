@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "zedo-release_amd", "csrc")
 
 MUTANTS = [
-    ("ZEDO_MUT_GN_EPS", "GroupNorm eps 1e-5 -> 2e-5 (zedo_gemm.hip epilogue; reference model.py:116)"),
+    ("ZEDO_MUT_GN_EPS", "GroupNorm eps 1e-5 -> 2e-5 (zedo_tile.h epilogue, both math modes; reference model.py:116)"),
     ("ZEDO_MUT_SDE_C", "c_i * (1 + 1e-4): score coefficient of x' = a x + c eps (zedo_capi.hip schedule; sde_lib.py:187-198)"),
     ("ZEDO_MUT_CONF2", "least-squares weight conf^4 -> conf^2 (zedo_geom.hip; simple_zeroshot_opt.py:85-88)"),
     ("ZEDO_MUT_SWITCH", "switch to the least-squares T one iteration late (zedo_capi.hip; run/opt_main.py:203-206)"),

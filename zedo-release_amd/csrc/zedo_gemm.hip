@@ -43,7 +43,7 @@
 //     (64x32 each, 74 registers, six per SIMD) for the residual layers, whose epilogue waits on a residual DMA.
 //     Larger tiles (256x128, 256x256) and four-fragment-set schedules are in the ubench variant table below; all
 //     measured equal or slower (profiles/ubench_gemm_*).
-//   * Tile quantisation: rows that do not fill a whole round of 2 workgroups x 256 CUs run as small
+//   * Tile quantisation: rows that do not fill a whole round of 3 workgroups x 256 CUs run as small
 //     tiles in the SAME launch (layer_pair_kernel): they back-fill CUs as the last big tiles drain.
 //   * Where the remaining ~8 % goes (ablations, profiles/ubench_gemm_49152_r01.txt): no epilogue
 //     -5.2 %, no in-loop DMA -1.7 %, neither: 150.8 TFLOP/s = 96.8 % of the measured MFMA peak.  The
@@ -593,9 +593,9 @@ static hipError_t launch_small(const LayerArgs &a, hipStream_t st) {
     return launch_cfg<128, 128, 2, 2, EPI, 2, 0, 32, SCHED_BIG, ZEDO_PLAIN_WPE>(a, st);
 }
 
-// N == 1024 or 512 (hidden / embedding width): 128x128 tiles, two workgroups per CU, on the rows that fill whole
-// rounds of the chip; the remainder rows as small tiles in the same launch (launch_pair).  716 / 729 us per plain /
-// residual layer at 49152 rows (144 / 141 TFLOP/s); 256x256 tiles (one workgroup per CU): 719 / 748 us.
+// N == 1024 or 512 (hidden / embedding width): 128x128 tiles on 16-deep K tiles, three workgroups per CU, on the rows that
+// fill whole rounds of the chip; the remainder rows as small tiles in the same launch (launch_pair).  734 / 739 us per
+// plain / residual layer at 50 752 rows (145 / 144 TFLOP/s); 256x256 tiles (one workgroup per CU): 719 / 748 us at 49 152.
 template <int EPI>
 static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
     // K <= 64 (pre_dense): almost no MFMA work per output, the layer is bound by writing the activation:

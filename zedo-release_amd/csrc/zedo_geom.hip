@@ -235,15 +235,6 @@ hipError_t launch_posemb(const float *t, int S, int Sp, float label_scale, float
     return hipGetLastError();
 }
 
-__global__ void add_rows_kernel(float *__restrict__ o, const float *__restrict__ a, const float *__restrict__ b, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) o[i] = a[i] + b[i];
-}
-hipError_t launch_add_bias_rows(float *b_sum, const float *b1, const float *b2, int n, hipStream_t st) {
-    hipLaunchKernelGGL(add_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b_sum, b1, b2, n);
-    return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------------
 // IPO: RotOpt + L1 reprojection loss + Adam, all iterations in registers
 // (run/opt_main.py:177-195, simple_zeroshot_opt.py:8-31, utils.py:59-88)

@@ -135,7 +135,6 @@ hipError_t launch_reproj_grad(const float *x, const float *geom, float *T, int s
 hipError_t launch_reproj_step_padded(float *xpad, const float *geom, float *T, int solve_T, int B, int N,
                                      long long row0, hipStream_t st);
 hipError_t launch_posemb(const float *t, int S, int Sp, float label_scale, float *pe, hipStream_t st);
-hipError_t launch_add_bias_rows(float *b_sum, const float *b1, const float *b2, int n, hipStream_t st);
 hipError_t launch_ipo_fit(const float *x0, const float *uv, const float *K, const int *h_keylist, int k,
                           int axes_mask, float ipo_T, float min_scale, float max_scale, int iters,
                           double normaliser, float *R, float *T, float *q, float *scale, float *state, int it_begin,

@@ -26,6 +26,9 @@ def build_parser(description, inference=False):
     p.add_argument("--synthetic", type=int, default=0, metavar="N",
                    help="no dataset / cluster / checkpoint files: N seeded synthetic poses, random-init weights")
     p.add_argument("--oil_iterations", type=int, default=None, help="override config.ZeDO.OIL_iterations")
+    p.add_argument("--math", choices=("f32", "f16x3"), default=None,
+                   help="arithmetic of the dense layers: f32 = exact fp32 MFMA (default), f16x3 = split-fp16 operands on the fp16 "
+                        "matrix pipe at fp32-level accuracy, ~2x faster (same as the ZEDO_MATH environment variable)")
     if inference:
         p.add_argument("--eval", action="store_true", default=None, help="evaluation mode")
         p.add_argument("--data", type=str, default=None, help="npz with db_2d, camera_param[, db_3d] ('wild' dataset)")
@@ -167,6 +170,8 @@ def run(args, inference=False):
     from zedo_hip.pipeline import Pipeline, ZeDOConfig, force_dist, gather_row_shards, shard_hypotheses, shard_rows
 
     config = load_config(args.config)
+    if getattr(args, "math", None):
+        os.environ["ZEDO_MATH"] = args.math          # read by zedo_hip.Weights when the model's device copy is built
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("this driver needs an MI355X: the sampling path has no CPU fallback")
