@@ -64,16 +64,18 @@ int zedo_weights_create(const float *h_params, size_t n_floats, int n_joints, in
                         int embed, int n_blocks, void *stream, zedo_weights_t **out);
 void zedo_weights_destroy(zedo_weights_t *w);
 
-/* ---- arithmetic of the four 1024x1024 hidden layers (opt-in) ---------------------------------------------------
+/* ---- arithmetic of the dense layers (opt-in) ----------------------------------------------------------------------
  * ZEDO_MATH_F32 (default): exact fp32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an fma chain per output.
- * ZEDO_MATH_F16X3: the same layers on the fp16 matrix pipe at fp32-level accuracy: every operand travels as two fp16
+ * ZEDO_MATH_F16X3: all six dense layers on the fp16 matrix pipe at fp32-level accuracy: every operand travels as two fp16
  *   pieces (a = ah + al + O(2^-24 |a|)), a 16-deep k block costs three fp16 MFMAs (al.bh + ah.bl + ah.bh, fp32
  *   accumulation); W carries a per-layer power-of-two scale undone exactly in the epilogue; activations between the
  *   hidden layers live in the same 4 bytes per element as two fp16 planes.  Per-product error = one fp32 rounding;
  *   measured max |y - y_fp64| of a layer 1.4e-6 (exact-fp32 kernel: 2.3e-6).  Results differ from ZEDO_MATH_F32 in the
- *   last bits, like any two fp32 implementations of the network do; every other kernel (pre_dense, post_dense + SDE
- *   update, reprojection, IPO, metric) is unchanged.  Requires activations below 65504 (they are O(10): SiLU of
- *   GroupNorm outputs).  zedo_weights_set_math builds the split copy of the hidden weights on first use and
+ *   last bits, like any two fp32 implementations of the network do; the geometry kernels (reprojection, IPO, metric) and the
+ *   fp32 pose state are unchanged.  Activations are stored as unscaled fp16 pieces: the call returns ZEDO_E_BADARG for a
+ *   network whose GroupNorm parameters could produce |activation| >= 32768 (bound: sum over the residual path of
+ *   max|gamma| sqrt(31) + max|beta|; trained checkpoints: O(10)) and for non-finite weights.
+ *   zedo_weights_set_math builds the split copy of the six weight matrices on first use and
  *   synchronises `stream`; the mode is a property of the handle and applies to every later call that takes it.
  */
 #define ZEDO_MATH_F32 0

@@ -568,3 +568,23 @@ def test_both_math_modes_are_fp32_accurate_against_the_fp64_oracle(zh, weights0)
     assert err["f16x3"][1] <= 1.25 * err["f32"][1] + 1e-8, err
     with pytest.raises(zh.ZedoError):
         W.set_math("bf16")
+
+
+def test_f16x3_is_refused_for_a_network_that_could_overflow_fp16(zh, weights0):
+    """The split-fp16 mode stores activations as unscaled fp16 pieces (max 65504).  A network whose GroupNorm parameters
+    allow activations near that range (bound: max|gamma| sqrt(31) + max|beta| along the residual path >= 32768) must be
+    refused when the mode is requested - loudly, not with an inf three layers later; so must non-finite weights.  The
+    exact-fp32 mode takes both."""
+    big = {k: v.copy() for k, v in weights0.items()}
+    big["b1_gnorm2.weight"][7] = 9000.0                    # 9000 * sqrt(31) = 5.0e4 on the residual path
+    W = zh.Weights(big, math="f32")
+    with pytest.raises(zh.ZedoError, match="bad argument"):
+        W.set_math("f16x3")
+    assert W.math == "f32"
+    nanw = {k: v.copy() for k, v in weights0.items()}
+    nanw["b2_dense1.weight"][3, 5] = np.inf
+    W2 = zh.Weights(nanw, math="f32")
+    with pytest.raises(zh.ZedoError):
+        W2.set_math("f16x3")
+    ok = zh.Weights(weights0, math="f32").set_math("f16x3")
+    assert ok.math == "f16x3"

@@ -34,6 +34,7 @@ struct zedo_weights {
     int math;
     uint16_t *d_W16;            // hidden [4][H][H/16][2][16] | pre_dense [H][4][2][16] | post_dense [XLD][H/16][2][16]
     float wmax_hid[6];          // max |w| of the four hidden layers, pre_dense, post_dense (from the host copy at create time)
+    float act_bound;            // upper bound of every activation |h| the network can produce (from gamma / beta, see zedo_weights_create)
     float unscale[6];           // 2^-wshift, same order
 };
 
@@ -199,9 +200,18 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     const float *p = h_params;
     auto next = [&](size_t n) { const float *q = p; p += n; return q; };
     float wmax_hid_tmp[6] = {0, 0, 0, 0, 0, 0};
+    // |SiLU(GroupNorm(.))| <= max|gamma| sqrt(31) + max|beta| per layer (a group of 32 normalised values has |v| <= sqrt(31));
+    // h = pre, then h += h2 twice: |h| <= bound[0] + bound[2] + bound[4]
+    float gn_bound[NLAYER] = {0, 0, 0, 0, 0};
+    auto gn_bound_of = [&](const float *g, const float *be, size_t n) {
+        float gm = 0.f, bm = 0.f;
+        for (size_t q = 0; q < n; ++q) { gm = std::fmax(gm, std::fabs(g[q])); bm = std::fmax(bm, std::fabs(be[q])); }
+        return gm * 5.5677643f + bm;     // sqrt(31)
+    };
     // pre_dense
     const float *w_pre = next(H * J3), *b_pre = next(H), *w_pre_t = next(H * E), *b_pre_t = next(H);
     const float *g_pre = next(H), *be_pre = next(H);
+    gn_bound[0] = gn_bound_of(g_pre, be_pre, H);
     const float *w_s = next(E * E), *b_s = next(E);
     for (size_t n = 0; n < H; ++n) memcpy(&img[o_Wpre + n * XLD], w_pre + n * J3, sizeof(float) * J3);
     for (size_t q = 0; q < H * J3; ++q) wmax_hid_tmp[4] = std::fmax(wmax_hid_tmp[4], std::fabs(w_pre[q]));
@@ -214,6 +224,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     for (int l = 1; l < NLAYER; ++l) {
         const float *w = next(H * H), *b = next(H), *wt = next(H * E), *bt = next(H), *g = next(H), *be = next(H);
         memcpy(&img[o_Whid0 + (size_t)(l - 1) * H * H], w, sizeof(float) * H * H);
+        gn_bound[l] = gn_bound_of(g, be, H);
         float wm = 0.f;
         for (size_t q = 0; q < H * H; ++q) wm = std::fmax(wm, std::fabs(w[q]));
         wmax_hid_tmp[l - 1] = wm;
@@ -235,6 +246,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     w->d_scratch = nullptr;
     w->math = ZEDO_MATH_F32; w->d_W16 = nullptr;
     for (int l = 0; l < 6; ++l) { w->wmax_hid[l] = wmax_hid_tmp[l]; w->unscale[l] = 1.0f; }
+    w->act_bound = std::fmax(std::fmax(gn_bound[1], gn_bound[3]), gn_bound[0] + gn_bound[2] + gn_bound[4]);
     hipError_t e = hipMalloc(&w->d_all, off * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&w->d_scratch, sizeof(float) * ((size_t)2 * ROW_PAD * EMB + ROW_PAD));
     if (e != hipSuccess) { (void)hipFree(w->d_all); delete w; return (int)e; }
@@ -270,6 +282,9 @@ extern "C" int zedo_weights_set_math(zedo_weights_t *w, int mode, void *stream) 
         hipStream_t st = (hipStream_t)stream;
         for (int l = 0; l < 6; ++l)
             if (!std::isfinite(w->wmax_hid[l])) return ZEDO_E_BADARG;          // a non-finite weight has no fp16 image
+        // activations are stored as UNSCALED fp16 pieces: refuse the mode for a network whose GroupNorm parameters allow an
+        // activation near the fp16 range (65504) instead of overflowing silently (trained checkpoints: O(10))
+        if (!(w->act_bound < 32768.0f)) return ZEDO_E_BADARG;
         const size_t per = (size_t)HID * HID * 2;                                 // uint16 per hidden layer
         HIPCHK(hipMalloc(&w->d_W16, sizeof(uint16_t) * (4 * per + (size_t)HID * XLD * 2 + (size_t)XLD * HID * 2)));
         hipError_t e = hipSuccess;
