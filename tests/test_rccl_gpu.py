@@ -79,9 +79,26 @@ if "MASTER_PORT" in os.environ:            # second process group of this proces
 out = os.path.join(sys.argv[1], "results.npy")
 res, errs = inf.main(inf.parse_args(["prog", "--config", cfg("h36m"), "--hypo", "2", "--synthetic", "30", "--oil_iterations", "10",
                                      "--eval", "--out", out]))
+# a sampler configuration OUTSIDE the fused pipeline (reverse-diffusion predictor): the step-wise loop, ranks sharing its
+# hypothesis loop, the all-gather of whole-hypothesis shards (gather_row_shards(lo=...))
+cfg2 = os.path.join(sys.argv[1], "cfg_rd.py")
+open(cfg2, "w").write(
+    "import importlib.util\n"
+    "_s = importlib.util.spec_from_file_location('base_cfg', r'%%s')\n"
+    "_m = importlib.util.module_from_spec(_s); _s.loader.exec_module(_m)\n"
+    "def get_config():\n"
+    "    c = _m.get_config()\n"
+    "    c.sampling.predictor = 'reverse_diffusion'\n"
+    "    return c\n" %% cfg("h36m"))
+if "MASTER_PORT" in os.environ:
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1]); s_.close()
+out2 = os.path.join(sys.argv[1], "results_rd.npy")
+torch.manual_seed(0)
+res2, _ = inf.main(inf.parse_args(["prog", "--config", cfg2, "--hypo", "3", "--synthetic", "12", "--oil_iterations", "5", "--out", out2]))
 import torch.distributed as dist
 print("RESULT " + json.dumps(dict(opt=[repr(p1), repr(p2)], inf=[repr(errs[0]), repr(errs[1])],
                                   sha=hashlib.sha256(np.load(out).tobytes()).hexdigest(), shape=list(res.shape),
+                                  sha_stepwise=hashlib.sha256(np.load(out2).tobytes()).hexdigest(), shape_stepwise=list(res2.shape),
                                   group_was_used=os.environ.get("ZEDO_FORCE_DIST") == "1")))
 '''
 
@@ -96,9 +113,9 @@ def test_drivers_on_rccl_are_bit_identical(tmp_path):
         out = _run([sys.executable, "-c", DRIVER % ROOT, str(d)], dist)
         res[dist] = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert res[True]["group_was_used"] and not res[False]["group_was_used"]
-    for k in ("opt", "inf", "sha", "shape"):
+    for k in ("opt", "inf", "sha", "shape", "sha_stepwise", "shape_stepwise"):
         assert res[False][k] == res[True][k], (k, res[False][k], res[True][k])
-    assert res[True]["shape"] == [30, 2, 17, 3]
+    assert res[True]["shape"] == [30, 2, 17, 3] and res[True]["shape_stepwise"] == [12, 3, 17, 3]
 
 
 INFER_SHARD = r'''

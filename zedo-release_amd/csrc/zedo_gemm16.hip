@@ -356,8 +356,8 @@ __device__ __forceinline__ void layer16_body(const Layer16Args &a, const int bid
 }
 
 // One launch, two tile shapes (as layer_pair_kernel of zedo_gemm.hip): workgroups [0, nbig) run BIG_M x BIG_N tiles on the rows
-// that fill whole rounds of the chip, the rest 64x128 tiles on the remainder rows, which back-fill CUs as the big tiles
-// drain.  Either count may be zero.
+// that fill whole rounds of the chip, the rest 64x64 tiles on the remainder rows, which back-fill CUs as the big tiles
+// drain (64x64: the tail of the launch is one small tile's latency, and a 64x64 tile's is the shortest).  Either count may be zero.
 // The big tile is 128 rows x 256 channels (four waves of 64 x 128, 230 registers, two workgroups per CU, 67 KB of LDS): on this
 // pipe every vector-memory instruction of a SIMD - LDS-DMA, load, store - serialises with its MFMAs at full price (65 cycles
 // per 1 KB LDS-DMA, 187 per 1 KB store; plain VALU is free; profiles/coissue_f16_r03.txt), so the layer's time is MFMA cycles +
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void layer16_pair_kernel(Layer16Args big, L
     const bool probe = big.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     if (probe) { c0 = clock64(); w0 = wall_clock64(); }
     if ((int)blockIdx.x < nbig) layer16_body<BIG_M, BIG_N, 2, 2, EPI, 2>(big, blockIdx.x, nbig);
-    else layer16_body<64, 128, 2, 2, EPI, 4>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+    else layer16_body<64, 64, 2, 2, EPI, 4>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     if (probe) { big.clk[0] = clock64() - c0; big.clk[1] = wall_clock64() - w0; }
 }
 
@@ -385,6 +385,14 @@ __global__ __launch_bounds__(256, 3) void layer16_pre_kernel(Layer16Args a) {
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void layer16_post_kernel(Layer16Args a) {   // 2: the fused reprojection keeps ~180 values per lane live (184 registers in zedo_gemm.hip too); no scratch
     layer16_body<64, 64, 2, 2, EPI, 8, 0>(a, blockIdx.x, gridDim.x);
+}
+
+// Small batches (up to 2048 rows: BASELINE configs[0] / [1]): a hidden layer is then a chain of 64 dependent k blocks per
+// workgroup and the chip is mostly empty; 64x64 tiles double the number of workgroups and halve each one's MFMA + DMA
+// issue time per block.  Same product order per element as every other shape.
+template <int EPI>
+__global__ __launch_bounds__(256, 4) void layer16_small_kernel(Layer16Args a) {
+    layer16_body<64, 64, 2, 2, EPI, 4, 0>(a, blockIdx.x, gridDim.x);
 }
 
 constexpr int MAX_DEVICES16 = 16;
@@ -406,7 +414,7 @@ static hipError_t launch_thin16(K kern, std::atomic<bool> *attr_done, size_t lds
 template <int EPI>
 static hipError_t launch_pair16(const Layer16Args &big, const Layer16Args &small, hipStream_t st) {
     constexpr size_t ring_big = 2 * (BIG_M + BIG_N) * 64, stage_big = (size_t)64 * BIG_N * 4, par_big = 3 * BIG_N * sizeof(float);
-    constexpr size_t ring_small = 4 * (128 + 64) * 64, stage_small = (size_t)64 * 128 * 4, par_small = 3 * 128 * sizeof(float);
+    constexpr size_t ring_small = 4 * (64 + 64) * 64, stage_small = (size_t)64 * 64 * 4, par_small = 3 * 64 * sizeof(float);
     constexpr size_t lds_big = (ring_big > stage_big ? ring_big : stage_big) + par_big;
     constexpr size_t lds_small = (ring_small > stage_small ? ring_small : stage_small) + par_small;
     constexpr size_t lds = lds_big > lds_small ? lds_big : lds_small;      // each tile shape finds its parameter block behind ITS body
@@ -420,7 +428,7 @@ static hipError_t launch_pair16(const Layer16Args &big, const Layer16Args &small
         if (e != hipSuccess) return e;
         attr_done[dev].store(true, std::memory_order_release);
     }
-    const int nbig = (big.Mp / BIG_M) * (big.N / BIG_N), nsmall = (small.Mp / 64) * (small.N / 128);
+    const int nbig = (big.Mp / BIG_M) * (big.N / BIG_N), nsmall = (small.Mp / 64) * (small.N / 64);
     if (nbig + nsmall == 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(nbig + nsmall), dim3(256), lds, st, big, small, nbig);
     return hipGetLastError();
@@ -457,6 +465,19 @@ hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st) {
         return hipErrorInvalidValue;
     }
     if (a.N % 128 || !a.X || !a.out) return hipErrorInvalidValue;
+    if (a.Mp <= 2048) {
+        constexpr size_t lds = (size_t)4 * (64 + 64) * 64 + 3 * 64 * sizeof(float);
+        const int grid = (a.Mp / 64) * (a.N / 64);
+        if (epilogue == EPI_GN_SILU) {
+            static std::atomic<bool> done[MAX_DEVICES16];
+            return launch_thin16(layer16_small_kernel<EPI_GN_SILU>, done, lds, grid, a, st);
+        }
+        if (epilogue == EPI_GN_SILU_RES) {
+            static std::atomic<bool> done[MAX_DEVICES16];
+            return launch_thin16(layer16_small_kernel<EPI_GN_SILU_RES>, done, lds, grid, a, st);
+        }
+        return hipErrorInvalidValue;
+    }
     if (epilogue == EPI_GN_SILU_RES && !a.res) return hipErrorInvalidValue;
     static std::atomic<int> cus_cached{0};
     int cus = cus_cached.load(std::memory_order_relaxed);
@@ -468,7 +489,7 @@ hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st) {
         cus_cached.store(cus, std::memory_order_relaxed);
     }
     // big tiles on the rows that fill whole rounds of 2 workgroups per CU; the remainder (and every batch smaller than
-    // one round) on 64x128 tiles: finer tiles spread a short launch over more CUs
+    // one round) on 64x64 tiles: finer tiles spread a short launch over more CUs
     if (a.N % BIG_N) return hipErrorInvalidValue;
     const int per_round = cus * 2 * BIG_M / (a.N / BIG_N);
     const int rows_big = (a.Mp / per_round) * per_round, rows_small = a.Mp - rows_big;
