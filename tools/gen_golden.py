@@ -923,6 +923,14 @@ def gen_driver_pw3d_full_oil64():
     _driver_oil_f64_from_pins("driver_pw3d_full", 1015, 50, 1000, 103, 19, "uniform", CACHE)
 
 
+def gen_driver_pw3d_full_b_oil64():
+    _driver_oil_f64_from_pins("driver_pw3d_full_b", 1015, 50, 1000, 203, 29, "ones", CACHE)
+
+
+def gen_driver_pw3d_full_c_oil64():
+    _driver_oil_f64_from_pins("driver_pw3d_full_c", 1015, 50, 1000, 307, 31, "uniform", CACHE)
+
+
 
 GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo, oil=gen_oil,
             eval=gen_eval, driver=gen_driver, datasets=gen_datasets,
@@ -930,8 +938,10 @@ GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo
             driver_h36m_full=gen_driver_h36m_full, driver_pw3d_full=gen_driver_pw3d_full,
             driver_h36m_full_f64=gen_driver_h36m_full_f64, driver_pw3d_full_f64=gen_driver_pw3d_full_f64,
             driver_pw3d_full_b=gen_driver_pw3d_full_b, driver_pw3d_full_c=gen_driver_pw3d_full_c,
-            driver_ipo_pins=gen_driver_ipo_pins, driver_pw3d_full_oil64=gen_driver_pw3d_full_oil64)
-SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64", "driver_pw3d_full_b", "driver_pw3d_full_c", "driver_ipo_pins", "driver_pw3d_full_oil64"}     # only with --only
+            driver_ipo_pins=gen_driver_ipo_pins, driver_pw3d_full_oil64=gen_driver_pw3d_full_oil64, driver_pw3d_full_b_oil64=gen_driver_pw3d_full_b_oil64,
+            driver_pw3d_full_c_oil64=gen_driver_pw3d_full_c_oil64)
+SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64", "driver_pw3d_full_b", "driver_pw3d_full_c", "driver_ipo_pins", "driver_pw3d_full_oil64", "driver_pw3d_full_b_oil64",
+        "driver_pw3d_full_c_oil64"}     # only with --only
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
