@@ -16,7 +16,7 @@
  *    library-owned device memory lives inside zedo_weights_t / zedo_schedule_t handles;
  *  - calls on distinct streams may run concurrently (one process per GPU is the intended use; a second device
  *    in the same process works: launch attributes are cached per device).  Process-wide state exists only
- *    outside the data path: the zedo_profile_* diagnostic (one session at a time, not thread safe) and the
+ *    outside the data path: the zedo_profile_* diagnostic (one session at a time; thread safe) and the
  *    ZEDO_CHUNK_ROWS environment value, read once;
  *  - rows are hypothesis-major: global row g = h*N + n (h = hypothesis, n = pose) - the order in
  *    which the reference's hypothesis loop produces them (run/opt_main.py:166-222).  A call may

@@ -1,11 +1,12 @@
 // C ABI of libzedo_hip.so (declared in include/zedo_hip.h): handle management, table building and the
 // launch sequences of the ZeDO hot path on gfx950.
-// Process-wide state, all of it outside the data path: the sampled-timing diagnostic (g_prof, one profiling
-// session at a time, not thread safe), the ZEDO_CHUNK_ROWS value read once, and per-device launch attributes
+// Process-wide state, all of it outside the data path: the sampled-timing diagnostic (g_prof: one profiling session at a
+// time; its bookkeeping is behind a mutex, the launch paths read one atomic flag), the ZEDO_CHUNK_ROWS value read once, and per-device launch attributes
 // cached in zedo_gemm.hip.  Everything a call computes with lives in the caller's buffers or the opaque handles.
 #include "../../include/zedo_hip.h"
 #include "zedo_internal.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -59,7 +60,8 @@ static int check_device_fwd() { return check_device(); }
 // itself, so the elapsed time is that kernel's duration as the stream saw it.  Off by default.
 namespace {
 struct Prof {
-    bool on = false;
+    std::atomic<bool> on{false};     // the only member the launch paths read without the lock
+    std::mutex mu;                   // every other member: sessions are serialised, sampling from several host threads is safe
     int every = 1;
     struct Pair { hipEvent_t a, b; int cls; };
     std::vector<Pair> pool;
@@ -75,7 +77,9 @@ struct ProfScope {
     hipStream_t st;
     long long *clk = nullptr;     // where the sampled launch may drop its clock pair
     ProfScope(int cls, hipStream_t s) : st(s) {
-        if (!g_prof.on) return;
+        if (!g_prof.on.load(std::memory_order_acquire)) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (!g_prof.on.load(std::memory_order_relaxed)) return;
         if ((g_prof.seen[cls]++ % g_prof.every) != 0 || g_prof.used >= g_prof.pool.size()) return;
         if (g_prof.d_clk && g_prof.used < g_prof.clk_cap) clk = g_prof.d_clk + 2 * g_prof.used;
         pr = &g_prof.pool[g_prof.used++];
@@ -95,6 +99,7 @@ extern "C" int zedo_probe_mfma_peak(int iters, double *h_tflops, double *h_shade
 
 extern "C" int zedo_profile_start(int sample_every, int max_samples) {
     if (sample_every < 1 || max_samples < 1) return ZEDO_E_BADARG;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     if (g_prof.pool.size() < (size_t)max_samples) {
         size_t old = g_prof.pool.size();
         g_prof.pool.resize(max_samples);
@@ -112,14 +117,15 @@ extern "C" int zedo_profile_start(int sample_every, int max_samples) {
     g_prof.used = 0;
     for (auto &v : g_prof.seen) v = 0;
     g_prof.every = sample_every;
-    g_prof.on = true;
+    g_prof.on.store(true, std::memory_order_release);
     return ZEDO_OK;
 }
 
 extern "C" double zedo_profile_shader_ghz(void) { return g_prof.ghz; }
 
 extern "C" int zedo_profile_stop(double *h_total_ms, long long *h_samples, long long *h_launches) {
-    g_prof.on = false;
+    g_prof.on.store(false, std::memory_order_release);
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     double tot[ZEDO_PROF_CLASSES] = {0, 0, 0, 0};
     long long cnt[ZEDO_PROF_CLASSES] = {0, 0, 0, 0};
     for (size_t i = 0; i < g_prof.used; ++i) {
