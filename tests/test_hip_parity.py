@@ -376,11 +376,13 @@ def test_min_mpjpe_nan_hypothesis_poisons_the_pose_like_numpy(zh, golden):
         assert best_h[3].item() == 2 and best_h[7].item() == 1
 
 
-@pytest.mark.parametrize("B", [1300, 2304, 4096, 5000, 7000, 8500, 10000, 16384])
+@pytest.mark.parametrize("B", [1300, 2304, 4096, 5000, 7000, 8500, 10000, 16384, 18000, 22000])
 def test_score_network_every_launch_shape(zh, W, weights0, B):
-    """Row counts that take each tile-selection branch of the dense layers (32 / 64 / 128-row tiles chosen by the
-    cost model below one round, the pair launch with a short and a long remainder, exact rounds); the oracle is
-    evaluated on a sample of rows (rows are independent) including the last ones."""
+    """Row counts that take each tile-selection branch of the dense layers - exact fp32: 32 / 64 / 128-row tiles chosen by the
+    cost model below one round, the pair launch with a short and a long remainder, exact rounds; f16x3: 64x64 tiles only (up to
+    2 048 rows), 128x128 tiles (below 8 192), a partly filled round of 128x256 tiles with and without a last 64-row strip, one
+    whole round, a whole round + a short remainder on 64x64 tiles (18 000) and + a long one on big tiles (22 000); the oracle
+    is evaluated on a sample of rows (rows are independent) including the last ones."""
     import zedo_oracle as O
     rng = np.random.default_rng(B)
     x = (0.3 * rng.standard_normal((B, 17, 3))).astype(np.float32)

@@ -364,9 +364,10 @@ __device__ __forceinline__ void layer16_body(const Layer16Args &a, const int bid
 // VMEM cycles, and the tile shape sets the VMEM share: LDS-DMA cycles / MFMA cycles = 43 (BM + BN) / (BM BN) = 0.68 for
 // 128x128, 0.51 for 128x256 (measured 341 -> 313 us per layer, profiles/ubench_f16x3_tiles_r03.txt), 0.34 for 256x256
 // (291 us, eight waves, one workgroup per CU: not adopted).
-constexpr int BIG_M = 128, BIG_N = 256;
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void layer16_pair_kernel(Layer16Args big, Layer16Args small, int nbig) {
+// BIG_N = 128: batches between 2 048 and 8 192 rows take 128x128 tiles (three workgroups per CU) - see launch_layer16.
+constexpr int BIG_M = 128;
+template <int EPI, int BIG_N>
+__global__ __launch_bounds__(256, BIG_N == 256 ? 2 : 3) void layer16_pair_kernel(Layer16Args big, Layer16Args small, int nbig) {
     long long c0 = 0, w0 = 0;
     const bool probe = big.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     if (probe) { c0 = clock64(); w0 = wall_clock64(); }
@@ -411,14 +412,14 @@ static hipError_t launch_thin16(K kern, std::atomic<bool> *attr_done, size_t lds
     return hipGetLastError();
 }
 
-template <int EPI>
+template <int EPI, int BIG_N>
 static hipError_t launch_pair16(const Layer16Args &big, const Layer16Args &small, hipStream_t st) {
     constexpr size_t ring_big = 2 * (BIG_M + BIG_N) * 64, stage_big = (size_t)64 * BIG_N * 4, par_big = 3 * BIG_N * sizeof(float);
     constexpr size_t ring_small = 4 * (64 + 64) * 64, stage_small = (size_t)64 * 64 * 4, par_small = 3 * 64 * sizeof(float);
     constexpr size_t lds_big = (ring_big > stage_big ? ring_big : stage_big) + par_big;
     constexpr size_t lds_small = (ring_small > stage_small ? ring_small : stage_small) + par_small;
     constexpr size_t lds = lds_big > lds_small ? lds_big : lds_small;      // each tile shape finds its parameter block behind ITS body
-    auto kern = layer16_pair_kernel<EPI>;
+    auto kern = layer16_pair_kernel<EPI, BIG_N>;
     static std::atomic<bool> attr_done[MAX_DEVICES16];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -464,7 +465,8 @@ hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st) {
         }
         return hipErrorInvalidValue;
     }
-    if (a.N % 128 || !a.X || !a.out) return hipErrorInvalidValue;
+    if (a.N % 256 || !a.X || !a.out) return hipErrorInvalidValue;
+    if (epilogue == EPI_GN_SILU_RES && !a.res) return hipErrorInvalidValue;
     if (a.Mp <= 2048) {
         constexpr size_t lds = (size_t)4 * (64 + 64) * 64 + 3 * 64 * sizeof(float);
         const int grid = (a.Mp / 64) * (a.N / 64);
@@ -478,7 +480,6 @@ hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st) {
         }
         return hipErrorInvalidValue;
     }
-    if (epilogue == EPI_GN_SILU_RES && !a.res) return hipErrorInvalidValue;
     static std::atomic<int> cus_cached{0};
     int cus = cus_cached.load(std::memory_order_relaxed);
     if (!cus) {
@@ -490,13 +491,30 @@ hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st) {
     }
     // big tiles on the rows that fill whole rounds of 2 workgroups per CU; the remainder (and every batch smaller than
     // one round) on 64x64 tiles: finer tiles spread a short launch over more CUs
-    if (a.N % BIG_N) return hipErrorInvalidValue;
-    const int per_round = cus * 2 * BIG_M / (a.N / BIG_N);
-    const int rows_big = (a.Mp / per_round) * per_round, rows_small = a.Mp - rows_big;
-    const Layer16Args big = rows_of16(a, 0, rows_big), small = rows_of16(a, rows_big, rows_small);
+    // Which rows get which tile (cycles of a CU: a 128x256 tile ~74k alone, a 128x128 tile ~41k, a 64x64 tile ~14.5k):
+    //   * whole rounds of 2 x 128x256 tiles per CU: big tiles;
+    //   * what is left after the whole rounds (or the whole batch, if it is smaller than a round): big tiles too from 5 120 rows
+    //     up (one more, partly filled round of big tiles then beats ~14 cycles per row of 64x64 tiles), 64x64 tiles below;
+    //   * a batch below 8 192 rows: 128x128 tiles on every whole 128 rows (more workgroups than 128x256, fewer DMA bytes than
+    //     64x64), 64x64 for a last 64-row strip.  Measured per hidden layer: 6 350 rows 55 us (128x128) / 61 (128x256) / 68
+    //     (64x64); 12 700 rows 118 / 96 / 125.
+    const int per_round = cus * 2 * BIG_M / (a.N / 256);
+    const int rows_whole = (a.Mp / per_round) * per_round;
+    const int rest = a.Mp - rows_whole;
+    if (rows_whole == 0 && rest < 8192) {
+        const int rows_mid = (a.Mp / BIG_M) * BIG_M;
+        const Layer16Args mid = rows_of16(a, 0, rows_mid), tail = rows_of16(a, rows_mid, a.Mp - rows_mid);
+        switch (epilogue) {
+            case EPI_GN_SILU: return launch_pair16<EPI_GN_SILU, 128>(mid, tail, st);
+            case EPI_GN_SILU_RES: return launch_pair16<EPI_GN_SILU_RES, 128>(mid, tail, st);
+        }
+        return hipErrorInvalidValue;
+    }
+    const int rows_big = rest >= 5120 ? rows_whole + (rest / BIG_M) * BIG_M : rows_whole;
+    const Layer16Args big = rows_of16(a, 0, rows_big), small = rows_of16(a, rows_big, a.Mp - rows_big);
     switch (epilogue) {
-        case EPI_GN_SILU: return launch_pair16<EPI_GN_SILU>(big, small, st);
-        case EPI_GN_SILU_RES: return launch_pair16<EPI_GN_SILU_RES>(big, small, st);
+        case EPI_GN_SILU: return launch_pair16<EPI_GN_SILU, 256>(big, small, st);
+        case EPI_GN_SILU_RES: return launch_pair16<EPI_GN_SILU_RES, 256>(big, small, st);
     }
     return hipErrorInvalidValue;
 }
