@@ -203,7 +203,6 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     //      its planes +] either 64 bytes of fp32 or 32 + 32 bytes of fp16 pieces - the same 64 bytes of the row either way
     if constexpr (GN) {
         constexpr int CG = BN / 16;              // 16-channel groups per stage row
-        static_assert((SR * CG) % NT == 0 || NT % (SR * CG) == 0, "write-out shape");
         float *S = reinterpret_cast<float *>(smem16);
         char *obase = reinterpret_cast<char *>(a.out) + (size_t)m0 * a.N * 4 + (size_t)n0 * 4;
         const char *rbase = reinterpret_cast<const char *>(a.res) + (size_t)m0 * a.N * 4 + (size_t)n0 * 4;
@@ -232,16 +231,32 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
                 }
             }
             __syncthreads();
-            for (int qi = tid; qi < SR * CG; qi += NT) {
-                const int sr = qi / CG, cg = qi % CG;
+            constexpr int ITEMS = (SR * CG + NT - 1) / NT;         // (row, 16-channel group) items per thread
+            static_assert((SR * CG) % NT == 0, "write-out shape");
+            // residual (EPI_GN_SILU_RES): ALL of this thread's loads first - the accumulators are dead by now, the registers are
+            // there - so that one memory round trip is exposed per phase, not one per item (`res` may alias `out`: the compiler
+            // must not, and does not, move a later item's load above an earlier item's store by itself)
+            f16x8 rres[EPI == EPI_GN_SILU_RES ? ITEMS : 1][4];
+            if constexpr (EPI == EPI_GN_SILU_RES) {
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+                    const int qi = it * NT + tid, sr = qi / CG, cg = qi % CG;
+                    const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
+                    const unsigned off = (unsigned)grow * (unsigned)a.N * 4u + (unsigned)cg * 64u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rres[it][q] = *reinterpret_cast<const f16x8 *>(rbase + off + 16 * q);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int qi = it * NT + tid, sr = qi / CG, cg = qi % CG;
                 const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
                 const unsigned off = (unsigned)grow * (unsigned)a.N * 4u + (unsigned)cg * 64u;
                 f32x4 v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4 *>(S + sr * BN + (((cg * 4 + q) ^ (sr & 7)) << 2));
                 if constexpr (EPI == EPI_GN_SILU_RES) {            // h = h + h2 (model.py:288): h from its planes, exactly h + l
-                    const f16x8 rh0 = *reinterpret_cast<const f16x8 *>(rbase + off), rh1 = *reinterpret_cast<const f16x8 *>(rbase + off + 16);
-                    const f16x8 rl0 = *reinterpret_cast<const f16x8 *>(rbase + off + 32), rl1 = *reinterpret_cast<const f16x8 *>(rbase + off + 48);
+                    const f16x8 &rh0 = rres[it][0], &rh1 = rres[it][1], &rl0 = rres[it][2], &rl1 = rres[it][3];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[0][e] += join_f16(rh0[e], rl0[e]);     v[1][e] += join_f16(rh0[4 + e], rl0[4 + e]);
