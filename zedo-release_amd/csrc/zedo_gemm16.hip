@@ -59,6 +59,13 @@ hipError_t launch_split_planes(const float *src, int rows, int cols, int ld, flo
     return hipGetLastError();
 }
 
+#ifdef ZEDO_UBENCH
+__device__ long long *g_timeline16 = nullptr;   // ubench only: 8 x int64 per workgroup {t0, t_loop, t_loop_end, t_end, hw_id, xcc_id}
+#define TL16_MARK(var) long long var = 0; if (g_timeline16 && threadIdx.x == 0) var = wall_clock64();
+#else
+#define TL16_MARK(var)
+#endif
+
 // One BM x BN output tile.  WM x WN waves, each TM x TN = (BM/WM) x (BN/WN); ring of NBUF 16-k blocks (2 for the big tile,
 // whose co-resident workgroups cover each other's DMA latency; 4 for the small tiles, which run at the end of a launch
 // or in small batches with the CU to themselves: a block's MFMAs (6 x 32 cycles) are far shorter than the DMA latency).
@@ -81,6 +88,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     extern __shared__ __attribute__((aligned(16))) char smem16[];
     float *Ps = reinterpret_cast<float *>(smem16 + BODY_B);           // [3][BN] bias | gamma | beta
 
+    TL16_MARK(tl0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN, li = lane & 31, kh = lane >> 5;
@@ -182,6 +190,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     }
     __syncthreads();
     fread(0, 0);
+    TL16_MARK(tl1)
     //   block kb in slot kb % NBUF, its fragments in set kb & 1:
     //       vmcnt((NBUF-2) blocks); barrier   <- every wave has read block kb (its fragments are in registers), block kb+1 has landed
     //       DMA(block kb+NBUF -> slot of kb);  read(block kb+1) -> the other set;  MFMA(block kb)
@@ -201,6 +210,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();           // drain the trailing DMA before the ring becomes the epilogue stage
+    TL16_MARK(tl2)
     if constexpr (LOOP_PRIO) __builtin_amdgcn_s_setprio(0);
 
     // ---- epilogue: GroupNorm + SiLU on the accumulators, staged through the LDS row-wise (chunk c of stage row sr at
@@ -363,6 +373,18 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
             if (j + 1 < TJ) __syncthreads();
         }
     }
+#ifdef ZEDO_UBENCH
+    if (g_timeline16) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store tail of this wave
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long *d = g_timeline16 + (size_t)blockIdx.x * 8;
+            d[0] = tl0; d[1] = tl1; d[2] = tl2; d[3] = wall_clock64();
+            d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+            d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        }
+    }
+#endif
 }
 
 // block -> tile, XCD aware (the hardware places block b on XCD b % 8): every XCD gets a contiguous range of tiles so that
