@@ -435,9 +435,51 @@ struct NextReproj {          // reprojection of the next loop iteration, fused i
     long long row0 = 0;
 };
 
+// ZEDO_MATH_F16X3: the same six layers on the fp16 matrix pipe (zedo_gemm16.hip).  h / h1 hold the activations as split-fp16
+// planes (the same 4 bytes per element); the pose state xpad, the time-bias rows and the SDE / reprojection epilogue stay fp32.
+static hipError_t mlp_layers_f16(const zedo_weights *w, const float *tb, float *xpad, float *h, float *h1, int Bp, bool sde,
+                                 float sa, float sc, float *eps_out, hipStream_t st, const NextReproj &nr) {
+    const size_t per = (size_t)HID * HID * 2;                 // uint16 per hidden weight matrix
+    const uint16_t *W_pre16 = w->d_W16 + 4 * per, *W_post16 = W_pre16 + (size_t)HID * XLD * 2;
+    hipError_t e;
+    {   // pre_dense + pre_gnorm + SiLU: X = the fp32 pose rows, split by the kernel
+        Layer16Args b{};
+        b.K = XLD; b.N = HID; b.Mp = Bp; b.Xf32 = xpad; b.W = W_pre16; b.unscale = w->unscale[4];
+        b.bias = tb; b.gamma = w->gamma[0]; b.beta = w->beta[0]; b.out = h; b.out_f32 = 0;
+        ProfScope ps(ZEDO_PROF_PRE, st);
+        e = launch_layer16(b, EPI_GN_SILU, st);
+    }
+    for (int blk = 0; blk < 2 && e == hipSuccess; ++blk) {
+        const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
+        Layer16Args b{};
+        b.K = HID; b.N = HID; b.Mp = Bp; b.out_f32 = 0;
+        b.X = reinterpret_cast<const uint16_t *>(h); b.W = w->d_W16 + (size_t)(l1 - 1) * per; b.unscale = w->unscale[l1 - 1];
+        b.bias = tb + (size_t)l1 * HID; b.gamma = w->gamma[l1]; b.beta = w->beta[l1]; b.out = h1;
+        { ProfScope ps(ZEDO_PROF_HIDDEN, st); b.clk = ps.clk; e = launch_layer16(b, EPI_GN_SILU, st); b.clk = nullptr; }
+        if (e != hipSuccess) break;
+        // h = h + h2: the residual comes from h's planes and the sum goes back into them, in place
+        b.X = reinterpret_cast<const uint16_t *>(h1); b.W = w->d_W16 + (size_t)(l2 - 1) * per; b.unscale = w->unscale[l2 - 1];
+        b.bias = tb + (size_t)l2 * HID; b.gamma = w->gamma[l2]; b.beta = w->beta[l2];
+        b.res = reinterpret_cast<const uint16_t *>(h); b.out = h;
+        { ProfScope ps(ZEDO_PROF_HIDDEN, st); b.clk = ps.clk; e = launch_layer16(b, EPI_GN_SILU_RES, st); b.clk = nullptr; }
+    }
+    if (e != hipSuccess) return e;
+    Layer16Args b{};
+    b.K = HID; b.N = XLD; b.Mp = Bp; b.X = reinterpret_cast<const uint16_t *>(h);
+    b.W = W_post16; b.unscale = w->unscale[5]; b.bias = w->b_post;
+    ProfScope ps(ZEDO_PROF_POST, st);
+    if (sde) {
+        b.xio = xpad; b.sde_a = sa; b.sde_c = sc;
+        b.rp_geom = nr.geom; b.rp_T = nr.T; b.rp_solve = nr.solve; b.rp_B = nr.B; b.rp_N = nr.N; b.rp_row0 = nr.row0;
+        return launch_layer16(b, EPI_SDE, st);
+    }
+    b.out = eps_out;
+    return launch_layer16(b, EPI_BIAS, st);
+}
+
 static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad, float *h, float *h1, int Bp, bool sde,
                              float sa, float sc, float *eps_out, hipStream_t st, const NextReproj &nr = NextReproj()) {
-    const bool f16 = w->math == ZEDO_MATH_F16X3;     // hidden layers on the fp16 matrix pipe; h / h1 then hold fp16 planes
+    if (w->math == ZEDO_MATH_F16X3) return mlp_layers_f16(w, tb, xpad, h, h1, Bp, sde, sa, sc, eps_out, st, nr);
     LayerArgs a{};
     a.Mp = Bp;
     // pre_dense + pre_gnorm + SiLU
@@ -445,36 +487,10 @@ static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad
     a.kzero8 = w->J3 <= XLD - 8;   // 51 real inputs: k = 56..63 are zero in xpad and in the padded weight
     a.bias = tb; a.gamma = w->gamma[0]; a.beta = w->beta[0]; a.out = h; a.ldo = HID;
     hipError_t e;
-    const size_t per16 = (size_t)HID * HID * 2;
-    if (f16) {
-        Layer16Args b{};
-        b.K = XLD; b.N = HID; b.Mp = Bp; b.Xf32 = xpad; b.W = w->d_W16 + 4 * per16; b.unscale = w->unscale[4];
-        b.bias = tb; b.gamma = w->gamma[0]; b.beta = w->beta[0]; b.out = h; b.out_f32 = 0;
-        ProfScope ps(ZEDO_PROF_PRE, st);
-        e = launch_layer16(b, EPI_GN_SILU, st);
-    } else {
-        ProfScope ps(ZEDO_PROF_PRE, st);
-        e = launch_layer(a, EPI_GN_SILU, st);
-    }
+    { ProfScope ps(ZEDO_PROF_PRE, st); e = launch_layer(a, EPI_GN_SILU, st); }
     a.kzero8 = 0;
     for (int blk = 0; blk < 2 && e == hipSuccess; ++blk) {
         const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
-        if (f16) {
-            // the same two layers: X, W and the activations between them as split-fp16 planes; the block's last layer adds
-            // the residual from h's planes and writes planes again, in place
-            const size_t per = (size_t)HID * HID * 2;
-            Layer16Args b{};
-            b.K = HID; b.N = HID; b.Mp = Bp;
-            b.X = reinterpret_cast<const uint16_t *>(h); b.W = w->d_W16 + (size_t)(l1 - 1) * per; b.unscale = w->unscale[l1 - 1];
-            b.bias = tb + (size_t)l1 * HID; b.gamma = w->gamma[l1]; b.beta = w->beta[l1]; b.out = h1; b.out_f32 = 0; b.res = nullptr;
-            { ProfScope ps(ZEDO_PROF_HIDDEN, st); b.clk = ps.clk; e = launch_layer16(b, EPI_GN_SILU, st); b.clk = nullptr; }
-            if (e != hipSuccess) break;
-            b.X = reinterpret_cast<const uint16_t *>(h1); b.W = w->d_W16 + (size_t)(l2 - 1) * per; b.unscale = w->unscale[l2 - 1];
-            b.bias = tb + (size_t)l2 * HID; b.gamma = w->gamma[l2]; b.beta = w->beta[l2];
-            b.res = reinterpret_cast<const uint16_t *>(h); b.out = h; b.out_f32 = 0;
-            { ProfScope ps(ZEDO_PROF_HIDDEN, st); b.clk = ps.clk; e = launch_layer16(b, EPI_GN_SILU_RES, st); b.clk = nullptr; }
-            continue;
-        }
         a.X = h; a.ldx = HID; a.W = w->W_hid[l1 - 1]; a.ldw = HID; a.K = HID; a.N = HID;
         a.bias = tb + (size_t)l1 * HID; a.gamma = w->gamma[l1]; a.beta = w->beta[l1]; a.out = h1; a.ldo = HID;
         { ProfScope ps(ZEDO_PROF_HIDDEN, st); a.clk = ps.clk; e = launch_layer(a, EPI_GN_SILU, st); a.clk = nullptr; }
@@ -484,19 +500,6 @@ static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad
         { ProfScope ps(ZEDO_PROF_HIDDEN, st); a.clk = ps.clk; e = launch_layer(a, EPI_GN_SILU_RES, st); a.clk = nullptr; }
     }
     if (e != hipSuccess) return e;
-    if (f16) {
-        Layer16Args b{};
-        b.K = HID; b.N = XLD; b.Mp = Bp; b.X = reinterpret_cast<const uint16_t *>(h);
-        b.W = w->d_W16 + 4 * per16 + (size_t)HID * XLD * 2; b.unscale = w->unscale[5]; b.bias = w->b_post;
-        ProfScope ps(ZEDO_PROF_POST, st);
-        if (sde) {
-            b.xio = xpad; b.sde_a = sa; b.sde_c = sc;
-            b.rp_geom = nr.geom; b.rp_T = nr.T; b.rp_solve = nr.solve; b.rp_B = nr.B; b.rp_N = nr.N; b.rp_row0 = nr.row0;
-            return launch_layer16(b, EPI_SDE, st);
-        }
-        b.out = eps_out;
-        return launch_layer16(b, EPI_BIAS, st);
-    }
     a.X = h; a.ldx = HID; a.W = w->W_post; a.ldw = HID; a.K = HID; a.N = XLD; a.bias = w->b_post;
     a.gamma = a.beta = nullptr; a.ldo = XLD;
     ProfScope ps(ZEDO_PROF_POST, st);
