@@ -165,7 +165,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     }
     const int KB = a.K / 16;                       // multiple of NBUF (checked at launch): the ring slot is a compile-time constant
     // hidden layers: waves inside the k loop outrank the co-resident workgroup's epilogue waves in the SIMD's arbitration
-    // (measured 337 -> 334 us per layer; on the thin layers it changes nothing)
+    // (measured 337 -> 334 us per layer; the other way round - epilogue above loop - 340 -> 345; on the thin layers nothing)
     constexpr bool LOOP_PRIO = (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) && !XF32;
     if constexpr (LOOP_PRIO) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
