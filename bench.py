@@ -262,7 +262,8 @@ def main():
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
 
-    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.dry_launch):
+    # ZEDO_BENCH_FORCE_LAUNCH=1: go through the launcher with one rank too (how the launcher itself is exercised on a one-GPU box)
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.dry_launch or os.environ.get("ZEDO_BENCH_FORCE_LAUNCH") == "1"):
         sys.exit(launch_ranks(a.gpus, [x for x in sys.argv[1:] if x != "--dry-launch"], dry=a.dry_launch))
 
     rank = int(os.environ.get("RANK", "0"))

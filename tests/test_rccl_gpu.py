@@ -149,3 +149,21 @@ def test_inference_driver_at_the_config4_shard_size_through_the_all_gather(tmp_p
     assert res[True]["group_was_used"] and not res[False]["group_was_used"]
     assert res[True]["shape"] == [12500, 50, 17, 3] and res[True]["finite"] and res[True]["errs"]
     assert res[False]["sha"] == res[True]["sha"]
+
+
+def test_bench_launcher_starts_its_rank_on_the_gpu():
+    """`python bench.py --gpus N` without torchrun: the parent (no GPU call) starts the ranks as fresh processes.  With one GPU
+    in the box the launcher is forced on for N = 1 (ZEDO_BENCH_FORCE_LAUNCH=1) and the rank takes the RCCL path
+    (ZEDO_FORCE_DIST=1): the child initialises the process group from the environment the launcher built, runs, and rank 0's
+    JSON line comes back through the parent, which exits 0."""
+    e = _env(False)
+    e.update(ZEDO_BENCH_FORCE_LAUNCH="1", ZEDO_FORCE_DIST="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--oil", "10", "--poses", "64",
+           "--hypo", "3", "--no-cpu-baseline", "--no-alt-mode"]
+    r = subprocess.run(cmd, env=e, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["config"]["rows_per_gpu"] == 64 * 3
+    # a rank that fails makes the launcher fail: an impossible workload (0 OIL steps is rejected by the schedule)
+    bad = subprocess.run(cmd[:-2] + ["--oil", "0"], env=e, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert bad.returncode != 0 and "rank 0 exited" in bad.stderr
