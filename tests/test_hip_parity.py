@@ -492,8 +492,20 @@ def test_bad_arguments_are_rejected(zh, W):
     with pytest.raises(zh.ZedoError):
         zh.Schedule(W, np.zeros(0, np.float32))
     with pytest.raises(zh.ZedoError):       # wrong parameter count
-        bad = dict(W_bad=None)
         zh.Weights({k: np.zeros(3, np.float32) for k in zh.param_names()})
+    # the entry points of ABI version 3, raw
+    geom = torch.zeros(3, 17, 8, device="cuda")
+    cnt = ctypes.c_int(0)
+    assert lib.zedo_reproj_degenerate(None, 3, 17, ctypes.cast(ctypes.byref(cnt), ctypes.c_void_p), None) == -1
+    assert lib.zedo_reproj_degenerate(P(geom), 0, 17, ctypes.cast(ctypes.byref(cnt), ctypes.c_void_p), None) == -1
+    assert lib.zedo_reproj_degenerate(P(geom), 3, 17, None, None) == -1
+    err = torch.zeros(6, dtype=torch.float64, device="cuda"); best = torch.zeros(3, dtype=torch.float64, device="cuda")
+    bh = torch.zeros(3, dtype=torch.int32, device="cuda")
+    assert lib.zedo_pose_min(None, 6, 3, 0, P(best), P(bh), None) == -1
+    assert lib.zedo_pose_min(P(err), 6, 3, -1, P(best), P(bh), None) == -1
+    assert lib.zedo_pose_min(P(err), 0, 3, 0, P(best), P(bh), None) == -1
+    assert lib.zedo_weights_set_math(None, 0, None) == -1 and lib.zedo_weights_set_math(W._h, 7, None) == -1
+    assert lib.zedo_weights_get_math(None) == -1 and lib.zedo_weights_get_math(W._h) == zh.MATH_MODES[W.math]
     with pytest.raises(zh.ZedoError):       # host tensor where a device tensor is required
         zh.reproj_prepare(torch.zeros(2, 17, 2), torch.zeros(2, 3, 3))
     assert b"argument" in lib.zedo_error_string(-1)
