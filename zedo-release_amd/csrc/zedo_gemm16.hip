@@ -405,7 +405,8 @@ __device__ __forceinline__ void layer16_body(const Layer16Args &a, const int bid
 // per 1 KB LDS-DMA, 187 per 1 KB store; plain VALU is free; profiles/coissue_f16_r03.txt), so the layer's time is MFMA cycles +
 // VMEM cycles, and the tile shape sets the VMEM share: LDS-DMA cycles / MFMA cycles = 43 (BM + BN) / (BM BN) = 0.68 for
 // 128x128, 0.51 for 128x256 (measured 341 -> 313 us per layer, profiles/ubench_f16x3_tiles_r03.txt), 0.34 for 256x256
-// (291 us, eight waves, one workgroup per CU: not adopted).
+// (291 us in the microbenchmark; eight waves, one workgroup per CU - tried in the product with the remainder as a launch of
+// its own: 0.354 ms per layer against 0.335, the epilogue of the only resident workgroup is fully exposed: not adopted).
 // BIG_N = 128: batches between 2 048 and 8 192 rows take 128x128 tiles (three workgroups per CU) - see launch_layer16.
 constexpr int BIG_M = 128;
 template <int EPI, int BIG_N>
