@@ -202,29 +202,15 @@ def rank_environments(n, port, base=None):
     return envs
 
 
-def launch_ranks(n, argv, dry=False):
-    """`python bench.py --gpus N` without a torchrun environment: start N fresh processes, one per GPU.  The parent makes
-    NO GPU call (device_count() does not initialise the runtime), so every child starts from a clean process; a failing
-    rank ends the others and the parent exits with its code."""
+def supervise(procs, poll_s=0.2):
+    """Wait for the rank processes: the first rank that exits non-zero ends the others (terminate, kill after 20 s) and
+    its code (1 for a signal) is returned; 0 when every rank exits 0."""
     import subprocess
-    visible = torch.cuda.device_count()
-    port = free_port()
-    envs = rank_environments(n, port)
-    cmd = [sys.executable, os.path.abspath(__file__)] + argv
-    if dry:
-        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")
-        print(json.dumps({"dry_launch": True, "gpus": n, "visible_gpus": visible, "cmd": cmd,
-                          "ranks": [{k: e[k] for k in keys} for e in envs]}), flush=True)
-        return 0
-    if visible < n:
-        print(f"bench.py: --gpus {n} but only {visible} GPU(s) are visible", file=sys.stderr)
-        return 2
-    procs = [subprocess.Popen(cmd, env=e) for e in envs]
     rc = 0
     try:
-        live = set(range(n))
+        live = set(range(len(procs)))
         while live and rc == 0:
-            time.sleep(0.2)
+            time.sleep(poll_s)
             for r in sorted(live):
                 c = procs[r].poll()
                 if c is not None:
@@ -242,6 +228,41 @@ def launch_ranks(n, argv, dry=False):
             except subprocess.TimeoutExpired:
                 pr.kill()
     return rc
+
+
+def launch_ranks(n, argv, dry=False, cmd=None):
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh processes, one per GPU.  The parent makes
+    no HIP call of its own (it only counts devices; the ranks are fresh child processes either way, never an exec of
+    this one), builds / verifies libzedo_hip.so ONCE before it starts them and exports ZEDO_NO_BUILD=1, so that the
+    ranks fail loudly instead of racing N `make`s; a failing rank ends the others and the parent exits with its code.
+    ZEDO_SHARE_DEVICE=1 + ZEDO_DIST_BACKEND=gloo: all N ranks on device 0 (rehearsal on a one-GPU box)."""
+    import subprocess
+    import zedo_build
+    share = os.environ.get("ZEDO_SHARE_DEVICE") == "1"
+    visible = torch.cuda.device_count()
+    port = free_port()
+    envs = rank_environments(n, port)
+    for e in envs:
+        e["ZEDO_NO_BUILD"] = "1"
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv if cmd is None else cmd
+    if dry:
+        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY", "ZEDO_NO_BUILD")
+        print(json.dumps({"dry_launch": True, "gpus": n, "visible_gpus": visible, "cmd": cmd,
+                          "library": zedo_build.LIB_PATH, "library_present": os.path.exists(zedo_build.LIB_PATH),
+                          "ranks": [{k: e[k] for k in keys} for e in envs]}), flush=True)
+        return 0
+    if visible < (1 if share else n):
+        print(f"bench.py: --gpus {n} but only {visible} GPU(s) are visible", file=sys.stderr)
+        return 2
+    if share and os.environ.get("ZEDO_DIST_BACKEND", "nccl").lower() != "gloo":
+        print("bench.py: ZEDO_SHARE_DEVICE=1 needs ZEDO_DIST_BACKEND=gloo (RCCL refuses two ranks on one device)", file=sys.stderr)
+        return 2
+    try:
+        zedo_build.ensure_library(allow_build=True)       # once, here - never in the ranks
+    except ImportError as e:
+        print(f"bench.py: {e}", file=sys.stderr)
+        return 3
+    return supervise([subprocess.Popen(cmd, env=e) for e in envs])
 
 
 def main():
@@ -270,20 +291,18 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and rank == 0:
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    import torch.distributed as dist
+    from zedo_hip import pipeline as zp
+    local = zp.local_device_index()        # LOCAL_RANK; device 0 for every rank with ZEDO_SHARE_DEVICE=1 (rehearsal)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    import torch.distributed as dist
-    from zedo_hip.pipeline import force_dist
-    use_dist = world > 1 or force_dist()   # ZEDO_FORCE_DIST=1: 1-rank test of the RCCL path
+    use_dist = world > 1 or zp.force_dist()   # ZEDO_FORCE_DIST=1: 1-rank test of the RCCL path
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        zp.init_dist(rank, world, dev, 29511)   # backend nccl == RCCL on ROCm (ZEDO_DIST_BACKEND=gloo: rehearsal transport)
 
     import zedo_hip as zh
     from zedo_hip.pipeline import Pipeline, ZeDOConfig, gather_row_shards, reduce_min_over_ranks, shard_rows
@@ -312,8 +331,13 @@ def main():
     gt_dev = torch.tensor(gt, dtype=torch.float64, device=dev) if wl["select"] != "gather" else None
     lo, rows = shard_rows(H * N_total, rank, world)
 
+    fail_rank = os.environ.get("ZEDO_BENCH_FAIL_RANK")      # test hook: that rank dies before the exchange step
+
     def one_pass():
         x, T = pipe.run(row_offset=lo, rows=rows)
+        if fail_rank is not None and rank == int(fail_rank):
+            torch.cuda.synchronize()
+            os._exit(9)
         if wl["select"] == "gather":     # run/inference.py:233-236: every hypothesis of every pose, on every rank
             return x, {"results": gather_row_shards(x, H * N_total)}
         sel = pipe.select(x, gt_dev, row_offset=lo)
@@ -329,7 +353,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
+            zp.barrier()
             torch.cuda.synchronize()
 
     def timed_run():
@@ -345,7 +369,7 @@ def main():
         prof = zh.profile_stop()
         if use_dist:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            zp.all_reduce(tt, dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt, prof, x, out
 
@@ -425,6 +449,7 @@ def main():
         line = {
             "metric": "poses/sec (1000-step sampler, H=50)", "value": round(poses_per_s, 3), "unit": "poses/s",
             "n_gpus": world, "rccl_ranks": (dist.get_world_size() if use_dist else 1),
+            "dist_backend": (dist.get_backend() if use_dist else None), "devices_shared": os.environ.get("ZEDO_SHARE_DEVICE") == "1",
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             # exact fp32 throughout by default; --math f16x3: fp32 state / epilogues / thin layers, hidden layers as split-fp16 products
@@ -473,7 +498,7 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if use_dist:
-        dist.barrier()
+        zp.barrier()
         dist.destroy_process_group()
 
 

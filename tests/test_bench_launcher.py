@@ -31,7 +31,7 @@ def test_dry_launch_describes_one_rank_per_gpu():
     assert len(ports) == 1 and 1024 < int(ports.pop()) < 65536
     for i, x in enumerate(d["ranks"]):
         assert x["RANK"] == x["LOCAL_RANK"] == str(i) and x["WORLD_SIZE"] == "4" and x["MASTER_ADDR"] == "127.0.0.1"
-        assert x["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        assert x["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and x["ZEDO_NO_BUILD"] == "1"     # the parent builds, never a rank
 
 
 def test_launcher_refuses_more_ranks_than_gpus_instead_of_benchmarking_one():
@@ -42,27 +42,64 @@ def test_launcher_refuses_more_ranks_than_gpus_instead_of_benchmarking_one():
 
 
 def test_launcher_propagates_a_failing_rank():
+    """bench.launch_ranks itself (the test used to re-implement its loop): two "ranks" that are plain python
+    processes - rank 1 fails with code 7, the launcher must end rank 0 (which would sleep for a minute) and return 7."""
     sys.path.insert(0, ROOT)
-    import bench
-    # two "ranks" that are plain python processes: rank 1 fails, the launcher must end rank 0 and return non-zero
-    envs = bench.rank_environments(2, bench.free_port(), base={"PATH": os.environ.get("PATH", "")})
-    assert [e["RANK"] for e in envs] == ["0", "1"] and all(e["WORLD_SIZE"] == "2" for e in envs)
-    code = "import os,sys,time; r=int(os.environ['RANK']); time.sleep(0.3 if r else 30); sys.exit(7 if r else 0)"
-    procs = [subprocess.Popen([sys.executable, "-c", code], env=e) for e in envs]
-    rc = None
     import time
-    t0 = time.time()
-    while rc is None and time.time() - t0 < 20:
-        for p in procs:
-            c = p.poll()
-            if c not in (None, 0):
-                rc = c
-        time.sleep(0.05)
-    for p in procs:
-        if p.poll() is None:
-            p.terminate()
-        p.wait(timeout=10)
-    assert rc == 7
+    import bench
+    code = "import os,sys,time; r=int(os.environ['RANK']); assert os.environ['ZEDO_NO_BUILD']=='1'; time.sleep(0.3 if r else 60); sys.exit(7 if r else 0)"
+    old = dict(os.environ)
+    os.environ.update(ZEDO_SHARE_DEVICE="1", ZEDO_DIST_BACKEND="gloo")      # no GPU count check on this CPU box
+    try:
+        real = bench.torch.cuda.device_count
+        bench.torch.cuda.device_count = lambda: 1
+        t0 = time.time()
+        rc = bench.launch_ranks(2, [], cmd=[sys.executable, "-c", code])
+        dt = time.time() - t0
+    finally:
+        bench.torch.cuda.device_count = real
+        os.environ.clear()
+        os.environ.update(old)
+    assert rc == 7 and dt < 30, (rc, dt)
+    # every rank exits 0 -> 0; a rank killed by a signal -> 1
+    procs = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(3)]
+    assert bench.supervise(procs, poll_s=0.05) == 0
+    procs = [subprocess.Popen([sys.executable, "-c", "import os,signal; os.kill(os.getpid(), signal.SIGKILL)"]),
+             subprocess.Popen([sys.executable, "-c", "import time; time.sleep(60)"])]
+    assert bench.supervise(procs, poll_s=0.05) == 1 and procs[1].poll() is not None
+
+
+def test_share_device_needs_the_gloo_transport():
+    sys.path.insert(0, os.path.join(ROOT, "zedo-release_amd"))
+    e = _env_without_ranks()
+    e.update(ZEDO_SHARE_DEVICE="1")
+    e.pop("ZEDO_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, 'zedo-release_amd'); from zedo_hip import pipeline as p; p.local_device_index()"],
+                       capture_output=True, text=True, env=e, cwd=ROOT, timeout=300)
+    assert r.returncode != 0 and "ZEDO_DIST_BACKEND=gloo" in r.stderr
+
+
+def test_missing_library_is_built_once_under_a_lock_or_refused(tmp_path):
+    """zedo_build.ensure_library: N ranks that find no library build it ONCE (exclusive lock; VERDICT r3: N concurrent
+    `make`s into the same objects), a rank of a launcher that has built already (ZEDO_NO_BUILD=1) fails loudly instead."""
+    import importlib.util
+    import shutil
+    pkg = tmp_path / "pkg"
+    (pkg / "csrc").mkdir(parents=True)
+    (pkg / "zedo_hip").mkdir()
+    shutil.copy(os.path.join(ROOT, "zedo-release_amd", "zedo_build.py"), pkg / "zedo_build.py")
+    # a stand-in Makefile that counts its invocations and takes a while, like hipcc does
+    (pkg / "csrc" / "Makefile").write_text("all:\n\techo x >> builds.log\n\tsleep 1\n\ttouch ../zedo_hip/libzedo_hip.so.tmp && mv ../zedo_hip/libzedo_hip.so.tmp ../zedo_hip/libzedo_hip.so\n")
+    code = f"import sys; sys.path.insert(0, {str(pkg)!r}); import zedo_build; print(zedo_build.ensure_library())"
+    e = _env_without_ranks()
+    e["ZEDO_NO_BUILD"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=60)
+    assert r.returncode != 0 and "ZEDO_NO_BUILD=1" in r.stderr and not (pkg / "csrc" / "builds.log").exists()
+    e.pop("ZEDO_NO_BUILD")
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=e, stdout=subprocess.PIPE, text=True) for _ in range(6)]
+    outs = [p.communicate(timeout=120)[0].strip() for p in procs]
+    assert all(p.returncode == 0 for p in procs) and all(o.endswith("libzedo_hip.so") for o in outs), outs
+    assert (pkg / "csrc" / "builds.log").read_text().count("x") == 1
 
 
 def test_workload_table_matches_the_baseline_configs():

@@ -28,6 +28,7 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(HERE, "ref_stubs"))
 sys.path.insert(0, "/root/reference")
 sys.path.insert(1, os.path.join(ROOT, "zedo-release_amd", "lib", "dataset"))
+sys.path.insert(2, os.path.join(ROOT, "tests"))
 
 import numpy as np
 import torch
@@ -721,19 +722,22 @@ def gen_driver_full():
 
 
 def _driver_full_size(tag, N, H, S, seed_pose, seed_cl, keylist, ipo_T, minT, conf_mode, dataset, cache_dir,
-                      dtype=torch.float32):
+                      dtype=torch.float32, perturb=0, weights=None):
     """opt_main.py:166-228 at a BASELINE configuration's stated size.  One hypothesis at a time like the reference;
     each finished hypothesis is parked under cache_dir so that an interrupted capture resumes.  Only small arrays
     are committed: the per-(pose, hypothesis) errors, per-pose best / argmin, dataset means, the IPO outcome as
     (rotation angle about z, depth scale) and the seeds of the inputs."""
-    w = syn.make_weights(seed=0)
+    w = weights if weights is not None else syn.make_weights(seed=0)
     m = ref_model(w, dtype)
     f64 = dtype == torch.float64          # the arbiter run: every tensor, RotOpt and the network in double
     d = syn.make_poses(N, seed=seed_pose, conf_mode=conf_mode, dtype3d=np.float64 if dataset == "h36m" else np.float32)
     cl = syn.make_clusters(H, seed=seed_cl)
     gt_2d, K = d["db_2d"], d["camera_param"]
+    if perturb:      # detections moved by -1/0/+1 ulp (syn.perturb_ulp): a member of the reference's own fp32 ensemble
+        gt_2d = gt_2d.copy()
+        gt_2d[:, :, :2] = syn.perturb_ulp(gt_2d[:, :, :2], perturb)
     os.makedirs(cache_dir, exist_ok=True)
-    batch_results, ang, scl, loss = [], [], [], []
+    batch_results, ang, scl, loss, cs_all, T_all = [], [], [], [], [], []
     import time
     for sid in range(H):
         f = os.path.join(cache_dir, f"{tag}_h{sid:02d}.npz")
@@ -750,6 +754,8 @@ def _driver_full_size(tag, N, H, S, seed_pose, seed_cl, keylist, ipo_T, minT, co
             np.savez(f, res=res, R=R, T=Tf, T0=T0, loss=ls)
             print(f"  {tag}: hypothesis {sid + 1}/{H} in {time.time() - t0:.0f} s", flush=True)
         batch_results.append(res)
+        cs_all.append(np.stack([R[:, 0, 0], R[:, 1, 0]], -1))
+        T_all.append(Tf[:, 0, :])
         ang.append(np.arctan2(R[:, 1, 0], R[:, 0, 0]))
         scl.append(Tf[:, 0, 2] / T0[:, 0, 2])
         loss.append(ls)
@@ -776,6 +782,17 @@ def _driver_full_size(tag, N, H, S, seed_pose, seed_cl, keylist, ipo_T, minT, co
         save(tag, N=np.int64(N), H=np.int64(H), S=np.int64(S), mpjpe=np.float64(p1), pa_mpjpe=np.float64(p2),
              best_p1=e1.min(1), best_p2=e2.min(1), argmin_p1=e1.argmin(1).astype(np.int32),
              argmin_p2=e2.argmin(1).astype(np.int32), inputs_sha=np.array(_sha(gt_2d, K, cl)))
+        return
+    if perturb or weights is not None:
+        # an ensemble member / another prior: the metric side + the IPO end state as quantile functions (tests/_ipo_summary.py)
+        import _ipo_summary as ips
+        x0c = (cl - cl[:, 0:1, :])[:, None]
+        sm = ips.summary(np.stack(cs_all), np.stack(T_all), x0c, gt_2d[:, :, :2], K, keylist, ipo_T)
+        save(tag, N=np.int64(N), H=np.int64(H), S=np.int64(S), perturb=np.int64(perturb), mpjpe=np.float64(p1), pa_mpjpe=np.float64(p2),
+             best_p1=e1.min(1).astype(np.float32), best_p2=e2.min(1).astype(np.float32),
+             argmin_p1=e1.argmin(1).astype(np.int8), argmin_p2=e2.argmin(1).astype(np.int8),
+             ipo_loss=np.array(loss, np.float32), inputs_sha=np.array(_sha(gt_2d, K, cl)),
+             weights_sha=np.array(syn.weights_checksum(w)), **sm)
         return
     save(tag, N=np.int64(N), H=np.int64(H), S=np.int64(S), seed_pose=np.int64(seed_pose), seed_cl=np.int64(seed_cl),
          conf_mode=np.array(conf_mode), dataset=np.array(dataset), keylist=np.array(keylist), ipo_T=np.float64(ipo_T),
@@ -833,6 +850,51 @@ def gen_driver_pw3d_full():
     (configs/optim/concat_pose_optimization_pw3d.py:72-81), PW3D.eval_multi.  ~45 CPU-minutes: run once
     (python tools/gen_golden.py --only driver_pw3d_full); excluded from the default sweep."""
     _driver_full_size("driver_pw3d_full", 1015, 50, 1000, 103, 19, list(range(17)), 8.0, 0.2, "uniform", "3dpw", CACHE)
+
+
+def gen_driver_pw3d_full_env():
+    """The reference's OWN fp32 reproducibility on configs[2]: the capture of gen_driver_pw3d_full repeated on detections
+    moved by -1/0/+1 ulp (syn.perturb_ulp, stream ZEDO_ENV_RUN = 1, 2, ...).  Thread count is NOT such a perturbation: the
+    reference's IPO and loop are bit-identical on 1, 4 and 8 threads here (probed).  One member = 40 CPU-minutes on 8
+    threads, 2.3 h on one; run the members as separate single-thread processes:
+        ZEDO_ENV_RUN=3 ZEDO_GOLDEN_THREADS=1 python tools/gen_golden.py --only driver_pw3d_full_env"""
+    run = int(os.environ["ZEDO_ENV_RUN"])
+    assert run > 0
+    _driver_full_size(f"driver_pw3d_full_env{run}", 1015, 50, 1000, 103, 19, list(range(17)), 8.0, 0.2, "uniform", "3dpw", CACHE,
+                      perturb=run)
+
+
+def gen_driver_pw3d_ipoens():
+    """The reference's IPO END STATE as a distribution: the 500 Adam iterations of run/opt_main.py:180-195 on configs[2]
+    (50 hypotheses x 1015 poses) for ZEDO_IPOENS_MEMBERS ulp-perturbed copies of the detections (syn.perturb_ulp streams
+    1..M; the IPO costs 2 s per hypothesis on a CPU, the 1000-step loop is not run), each summarised by the quantile
+    functions of tests/_ipo_summary.py.  ZEDO_IPOENS_DRAW = a | b | c selects the capture (default a)."""
+    import _ipo_summary as ips
+    draw = os.environ.get("ZEDO_IPOENS_DRAW", "a")
+    M = int(os.environ.get("ZEDO_IPOENS_MEMBERS", "16"))
+    tag, seed_pose, seed_cl, conf_mode = {"a": ("driver_pw3d_full", 103, 19, "uniform"), "b": ("driver_pw3d_full_b", 203, 29, "ones"),
+                                          "c": ("driver_pw3d_full_c", 307, 31, "uniform")}[draw]
+    N, H, keylist, ipo_T, minT = 1015, 50, list(range(17)), 8.0, 0.2
+    d = syn.make_poses(N, seed=seed_pose, conf_mode=conf_mode)
+    cl = syn.make_clusters(H, seed=seed_cl)
+    K = d["camera_param"]
+    assert str(np.load(os.path.join(OUT, tag + ".npz"))["inputs_sha"]) == _sha(d["db_2d"], K, cl)
+    x0c = (cl - cl[:, 0:1, :])[:, None]
+    rows = []
+    import time
+    for run in range(1, M + 1):
+        t0 = time.time()
+        uv = syn.perturb_ulp(d["db_2d"][:, :, :2], run)
+        cs, Ts = [], []
+        for sid in range(H):
+            noisy = (torch.ones((N, 17, 3)) * torch.tensor(cl - cl[:, 0:1, :])[sid:sid + 1])
+            r = run_ref_ipo(noisy.numpy(), uv, K, "z", keylist, ipo_T, minT, 2.0, 500, trace_upto=1)
+            cs.append(np.stack([r["R"][:, 0, 0], r["R"][:, 1, 0]], -1))
+            Ts.append(r["T"][:, 0, :])
+        rows.append(ips.summary(np.stack(cs), np.stack(Ts), x0c, uv, K, keylist, ipo_T))
+        print(f"  {tag} ipo ensemble: member {run}/{M} in {time.time() - t0:.0f} s", flush=True)
+    save(tag + "_ipoens", members=np.arange(1, M + 1), inputs_sha=np.array(_sha(d["db_2d"], K, cl)),
+         **{k: np.stack([np.asarray(r[k]) for r in rows]) for k in rows[0]})
 
 
 def _driver_ipo_pin(tag, N, H, seed_pose, seed_cl, keylist, ipo_T, minT, conf_mode, dataset, cache_dir):
@@ -939,9 +1001,10 @@ GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo
             driver_h36m_full_f64=gen_driver_h36m_full_f64, driver_pw3d_full_f64=gen_driver_pw3d_full_f64,
             driver_pw3d_full_b=gen_driver_pw3d_full_b, driver_pw3d_full_c=gen_driver_pw3d_full_c,
             driver_ipo_pins=gen_driver_ipo_pins, driver_pw3d_full_oil64=gen_driver_pw3d_full_oil64, driver_pw3d_full_b_oil64=gen_driver_pw3d_full_b_oil64,
-            driver_pw3d_full_c_oil64=gen_driver_pw3d_full_c_oil64)
+            driver_pw3d_full_c_oil64=gen_driver_pw3d_full_c_oil64, driver_pw3d_full_env=gen_driver_pw3d_full_env,
+            driver_pw3d_ipoens=gen_driver_pw3d_ipoens)
 SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64", "driver_pw3d_full_b", "driver_pw3d_full_c", "driver_ipo_pins", "driver_pw3d_full_oil64", "driver_pw3d_full_b_oil64",
-        "driver_pw3d_full_c_oil64"}     # only with --only
+        "driver_pw3d_full_c_oil64", "driver_pw3d_full_env", "driver_pw3d_ipoens"}     # only with --only
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -33,18 +33,27 @@ def hypothesis_min(preds, gt_centred, protocol2, valid_ind=None, row_offset=0, d
     if valid_ind is not None:
         # hypotheses not listed for a pose do not take part: their error becomes +inf ON THE DEVICE, for whatever
         # shard of the rows this rank holds, and the per-pose minimum is taken again (zedo_pose_min)
-        B = rows.shape[0]
-        H = -(-(int(row_offset) + B) // N)
-        ok = np.zeros((H, N), dtype=bool)
-        for n in range(N):
-            v = [int(h) for h in valid_ind[n] if 0 <= int(h) < H]
-            ok[v, n] = True
-        ok_rows = torch.as_tensor(ok.reshape(-1)[int(row_offset):int(row_offset) + B], device=device)
+        ok_rows = valid_rows_mask(valid_ind, N, int(row_offset), rows.shape[0], device)
         err = torch.where(ok_rows, err, torch.full_like(err, float("inf")))
         best, idx = zedo_hip.pose_min(err, N, row_offset)
         idx = torch.where(torch.isinf(best), torch.full_like(idx, -1), idx)     # nothing listed on this rank for the pose
     best, idx = reduce_min_over_ranks(best, idx)
     return best.cpu().numpy(), idx.cpu().numpy()
+
+
+def valid_rows_mask(valid_ind, N, row_offset, B, device):
+    """bool [B] on `device`: row g = row_offset + i (g = h*N + n) is True when hypothesis h is listed in valid_ind[n].
+    One flat index list built on the host (no per-pose Python statement: the full H36M test set has 567 040 poses) and
+    ONE scatter on the device."""
+    import itertools
+    lens = np.fromiter((len(v) for v in valid_ind), dtype=np.int64, count=N)
+    h = np.fromiter(itertools.chain.from_iterable(valid_ind), dtype=np.int64, count=int(lens.sum()))
+    g = h * N + np.repeat(np.arange(N, dtype=np.int64), lens) - int(row_offset)
+    g = g[(h >= 0) & (g >= 0) & (g < B)]
+    ok = torch.zeros((B,), dtype=torch.bool, device=device)
+    if g.size:
+        ok[torch.as_tensor(g, device=device)] = True
+    return ok
 
 
 def subsample(preds, gt_centred, sample_interval, row_offset=0):

@@ -138,3 +138,18 @@ def make_poses(N, seed=0, conf_mode="ones", rot_z=True, dtype3d=np.float32):
         raise ValueError(conf_mode)
     db_2d = np.concatenate([uv, conf[..., None]], -1).astype(np.float32)
     return dict(db_2d=db_2d, db_3d=cam.astype(dtype3d), camera_param=K.astype(np.float32))
+
+
+def perturb_ulp(a, seed):
+    """A copy of the float32 array ``a`` with every element moved by -1, 0 or +1 unit in the last place
+    (equiprobable, Philox stream of ``seed``).  The end-to-end loop is chaotic in the IPO's last iterate (Adam on an
+    L1 loss, reference run/opt_main.py:180-195): inputs that differ in the last bit re-draw it, in the reference and
+    here alike - the ensembles of tests/golden/driver_pw3d_full_env*.npz (reference) and of
+    tests/test_ensemble_gpu.py (HIP) are built from detections perturbed this way; ``seed`` 0 returns ``a`` itself."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if int(seed) == 0:
+        return a.copy()
+    s = _rng(seed, 30).integers(-1, 2, size=a.shape)
+    up = np.nextafter(a, np.float32(np.inf), dtype=np.float32)
+    dn = np.nextafter(a, np.float32(-np.inf), dtype=np.float32)
+    return np.where(s > 0, up, np.where(s < 0, dn, a)).astype(np.float32)

@@ -167,7 +167,8 @@ def run(args, inference=False):
     from lib.algorithms.advanced import sde_lib
     from lib.algorithms.advanced.model import ScoreModelFC_Adv
     from lib.algorithms.ema import ExponentialMovingAverage
-    from zedo_hip.pipeline import Pipeline, ZeDOConfig, force_dist, gather_row_shards, shard_hypotheses, shard_rows
+    from zedo_hip.pipeline import (Pipeline, ZeDOConfig, barrier, force_dist, gather_row_shards, init_dist,
+                                   local_device_index, shard_hypotheses, shard_rows)
 
     config = load_config(args.config)
     if getattr(args, "math", None):
@@ -175,14 +176,11 @@ def run(args, inference=False):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("this driver needs an MI355X: the sampling path has no CPU fallback")
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local_device_index())      # LOCAL_RANK (device 0 for every rank with ZEDO_SHARE_DEVICE=1)
     device = torch.device("cuda", torch.cuda.current_device())
     use_dist = world > 1 or force_dist()      # ZEDO_FORCE_DIST=1: the RCCL path with one rank (tests)
     if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
+        init_dist(rank, world, device, 29512)     # backend nccl == RCCL on ROCm (ZEDO_DIST_BACKEND=gloo: rehearsal transport)
 
     if args.synthetic:
         from lib.dataset import synthetic as syn
@@ -248,6 +246,6 @@ def run(args, inference=False):
         errs = (p1, p2)
     if use_dist:
         import torch.distributed as dist
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
     return batch_results, errs

@@ -11,19 +11,15 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzedo_hip.so")
+import sys as _sys
+if os.path.dirname(_HERE) not in _sys.path:
+    _sys.path.insert(0, os.path.dirname(_HERE))
+import zedo_build as _zb
 
-if not os.path.exists(LIB_PATH):
-    # Not a fallback: the only way to get the hot path is to compile the HIP sources (hipcc cross-compiles
-    # gfx950 without a GPU).  If that is impossible, fail loudly.
-    import subprocess
-    _csrc = os.path.join(os.path.dirname(_HERE), "csrc")
-    try:
-        subprocess.run(["make", "-C", _csrc, "-j4"], check=True, stdout=subprocess.DEVNULL)
-    except Exception as e:  # noqa: BLE001
-        raise ImportError(
-            f"{LIB_PATH} is missing and `make -C {_csrc}` failed ({e}).  Build it with "
-            "__graft_entry__.build().  The ZeDO hot path has no CPU or PyTorch fallback.") from e
+# Not a fallback: the only way to get the hot path is to compile the HIP sources (hipcc cross-compiles gfx950 without a
+# GPU).  A missing library is built once, under a lock (N ranks importing at the same time build it once); with
+# ZEDO_NO_BUILD=1 (ranks of a launcher that has built already) or when the build fails this raises ImportError.
+LIB_PATH = _zb.ensure_library()
 
 _lib = ctypes.CDLL(LIB_PATH)
 

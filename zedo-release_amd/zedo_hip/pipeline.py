@@ -118,6 +118,73 @@ def force_dist():
     return os.environ.get("ZEDO_FORCE_DIST") == "1" or os.environ.get("ZEDO_BENCH_FORCE_DIST") == "1"
 
 
+def dist_backend():
+    """Transport of the exchange step.  Default `nccl` (= RCCL on ROCm, one rank per GPU, over xGMI).
+    ZEDO_DIST_BACKEND=gloo is a REHEARSAL transport: the same collectives on host copies of the (<= 8 KB per pose vector,
+    or the gathered rows) tensors, so that N real ranks - N processes, N process-group members, every rank on its own
+    row shard - can run where RCCL cannot: RCCL refuses two ranks on one device, and a one-GPU box is all a test has."""
+    b = os.environ.get("ZEDO_DIST_BACKEND", "nccl").strip().lower() or "nccl"
+    if b not in ("nccl", "gloo"):
+        raise ValueError(f"ZEDO_DIST_BACKEND={b!r}: expected nccl or gloo")
+    return b
+
+
+def local_device_index():
+    """The GPU of this rank: LOCAL_RANK - or device 0 for every rank with ZEDO_SHARE_DEVICE=1 (N ranks rehearsed on one
+    MI355X; only with ZEDO_DIST_BACKEND=gloo)."""
+    if os.environ.get("ZEDO_SHARE_DEVICE") == "1":
+        if dist_backend() != "gloo":
+            raise ValueError("ZEDO_SHARE_DEVICE=1 needs ZEDO_DIST_BACKEND=gloo: RCCL does not accept two ranks on one device")
+        return 0
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_dist(rank, world, device, default_port):
+    """One process group per run: backend nccl (RCCL) bound to this rank's device, or the gloo rehearsal transport."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(default_port))
+    if dist_backend() == "gloo":
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
+    return dist
+
+
+def _host_transport(t):
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_reduce(t, op):
+    """dist.all_reduce in place; over the gloo rehearsal transport a device tensor travels as a host copy."""
+    import torch.distributed as dist
+    if _host_transport(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
+def all_gather_into_tensor(out, t):
+    import torch.distributed as dist
+    if _host_transport(t):
+        ho = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(ho, t.cpu())
+        out.copy_(ho)
+    else:
+        dist.all_gather_into_tensor(out, t)
+    return out
+
+
+def barrier():
+    import torch.distributed as dist
+    dist.barrier()
+
+
 def dist_active():
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_dist())
@@ -134,9 +201,9 @@ def reduce_min_over_ranks(best, idx):
     big = 2 ** 31 - 1
     key = torch.where(torch.isnan(best), torch.full_like(best, float("-inf")), best)
     g = key.clone()
-    dist.all_reduce(g, op=dist.ReduceOp.MIN)
+    all_reduce(g, dist.ReduceOp.MIN)
     cand = torch.where((key == g) & (idx >= 0), idx.to(torch.int64), torch.full_like(idx, big, dtype=torch.int64))
-    dist.all_reduce(cand, op=dist.ReduceOp.MIN)
+    all_reduce(cand, dist.ReduceOp.MIN)
     cand = torch.where(cand == big, torch.full_like(cand, -1), cand)        # a pose no rank holds
     g = torch.where(g == float("-inf"), torch.full_like(g, float("nan")), g)
     return g, cand.to(torch.int32)
@@ -160,13 +227,13 @@ def gather_row_shards(x_local, total_rows, lo=None):
     else:
         mine = torch.tensor([int(lo), x_local.shape[0]], dtype=torch.int64, device=x_local.device)
         allc = torch.empty((world * 2,), dtype=torch.int64, device=x_local.device)
-        dist.all_gather_into_tensor(allc, mine)
+        all_gather_into_tensor(allc, mine)
         counts = allc.reshape(world, 2).cpu().tolist()
         per = max(1, max(c for _, c in counts))
     pad = torch.zeros((per,) + tail, dtype=x_local.dtype, device=x_local.device)
     pad[:x_local.shape[0]] = x_local
     out = torch.empty((world * per,) + tail, dtype=x_local.dtype, device=x_local.device)
-    dist.all_gather_into_tensor(out, pad)
+    all_gather_into_tensor(out, pad)
     if counts is None:
         return out[:total_rows]
     full = torch.empty((total_rows,) + tail, dtype=x_local.dtype, device=x_local.device)
