@@ -139,17 +139,36 @@ def cpu_baseline(weights, cfg_kw, seed):
                        f"extrapolated to H={N_HYPO}, S={S_OIL}")
 
 
+def f16x3_tile_split(rows_launch, cus=256):
+    """Rows per tile shape of one split-fp16 hidden-layer launch: the branch logic of zedo_gemm16.hip::launch_layer16,
+    restated (rows padded to 64).  -> [(BM, BN, rows), ...]"""
+    mp = -(-int(rows_launch) // 64) * 64
+    if mp <= 2048:
+        return [(64, 64, mp)]
+    per_round = cus * 2 * 128 // (1024 // 256)
+    whole = (mp // per_round) * per_round
+    rest = mp - whole
+    if whole == 0 and rest < 8192:
+        mid = (mp // 128) * 128
+        return [(128, 128, mid), (64, 64, mp - mid)]
+    big = whole + (rest // 128) * 128 if rest >= 5120 else whole
+    return [(128, 256, big), (64, 64, mp - big)]
+
+
 def roofline_f16x3(h2, rows_launch):
     """Roofline object of the split-fp16 hidden layer: three fp16 MFMAs (al.bh + ah.bl + ah.bh) per fp32 product block:
     ISSUED flop against the dense fp16 peak, plus the bytes the tiles pull through LDS-DMA against what that path
-    sustains (the binding resource)."""
+    sustains (the binding resource).  The tile model follows the launch's own shape choice (f16x3_tile_split)."""
     issued = 3 * 2.0 * rows_launch * 1024 * 1024
     ghz = h2.get("shader_clock_ghz") or 0.0
-    dma_bytes = (rows_launch / 128.0) * 4 * 64 * (128 + 256) * 64      # row tiles x column tiles x k blocks x 24 KB (128 x 256 tiles)
+    split = [t for t in f16x3_tile_split(rows_launch) if t[2] > 0]
+    # per tile and 16-deep k block both operands' planes: (BM + BN) rows x 64 bytes; 64 k blocks; 1024 / BN column tiles
+    dma_bytes = sum((r / bm) * (1024 / bn) * (bm + bn) * 64 * 64 for bm, bn, r in split)
+    shape = " + ".join(f"{bm}x{bn} tiles on {r} rows" for bm, bn, r in split)
     t = h2["avg_ms"] * 1e-3
-    return dict(bound="mfma", kernel="zedo::layer16_pair_kernel (128x256 tiles + 64x128 remainder tiles, split-fp16 operands, 3 x v_mfma_f32_32x32x16_f16 per 16-k block)",
+    return dict(bound="mfma", kernel=f"zedo::layer16_pair_kernel / layer16_small_kernel ({shape}; split-fp16 operands, 3 x v_mfma_f32_32x32x16_f16 per 16-k block)",
                 achieved=round(issued / t / 1e12, 1), peak=2500.0, unit="TFLOP/s", frac=round(issued / t / 1e12 / 2500.0, 4),
-                traffic=None, fp32_equivalent_tflops=round(2.0 * rows_launch * 1024 * 1024 / t / 1e12, 1),
+                traffic=f16x3_traffic(rows_launch), fp32_equivalent_tflops=round(2.0 * rows_launch * 1024 * 1024 / t / 1e12, 1),
                 avg_launch_ms=round(h2["avg_ms"], 4), sampled_launches=h2["samples"], launches=h2["launches"],
                 kernel_shader_clock_ghz=round(ghz, 3) if ghz else None,
                 frac_at_kernel_clock=(round(issued / t / 1e12 / (2500.0 * ghz / 2.4), 4) if ghz else None),
@@ -160,6 +179,16 @@ def roofline_f16x3(h2, rows_launch):
                 note="power management holds the shader clock near 1.8 GHz under the dense fp16 MFMA stream; on this pipe a SIMD's "
                      "vector-memory instructions serialise with its MFMAs (65 cycles per 1 KB LDS-DMA, 187 per 1 KB store, "
                      "profiles/coissue_f16_r03.txt): vmem_model_ms = (MFMA + LDS-DMA + store cycles) / 1024 SIMDs at the kernel's clock")
+
+
+def f16x3_traffic(rows_launch):
+    """HBM-side bytes per split-fp16 hidden launch from the committed counter pass (profiles/hbm_traffic_f16x3.json,
+    tools/pmc_f16x3.sh), for the launch shape it was collected on; None otherwise."""
+    tp = os.path.join(ROOT, "profiles", "hbm_traffic_f16x3.json")
+    if not os.path.exists(tp):
+        return None
+    tj = json.load(open(tp))
+    return tj.get("hidden_dense_bytes_per_launch") if int(tj.get("rows_launch", -1)) == int(rows_launch) else None
 
 
 def selection_digest(out):
@@ -424,6 +453,7 @@ def main():
                                               if hid.get("shader_clock_ghz") else None),
                         frac_of_box_peak=round(ach / box_tf, 4),
                         flop_per_launch=flop_launch, avg_launch_ms=round(hid["avg_ms"], 4),
+                        avg_launch_ms_bracketed=round(hid["avg_ms_raw"], 4), event_bracket_ms=round(hid.get("bracket_ms") or 0.0, 5),
                         sampled_launches=hid["samples"], launches=hid["launches"],
                         mfma_busy_pmc=mfma_busy,   # SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles
                         # achieved / avg_launch_ms are measured in THIS run; traffic and mfma_busy_pmc are not:
@@ -469,6 +499,14 @@ def main():
             **quality,
             "roofline": roof,
             "kernel_time_ms_sampled_avg": {k: (round(v["avg_ms"], 4) if v["avg_ms"] else None) for k, v in prof.items()},
+            # self-check (tests/test_rccl_gpu.py asserts it): the sampled per-class kernel times, each less the cost of an
+            # empty event bracket on the same stream (event_bracket_ms; kernel_time_ms_sampled_raw keeps the bracketed
+            # values), scaled to ALL launches of the timed region, per OIL iteration - against the wall time per OIL
+            # iteration, which also contains the IPO, the selection and the gaps between launches: sum <= wall
+            "kernel_time_ms_sampled_raw": {k: (round(v["avg_ms_raw"], 4) if v["avg_ms_raw"] else None) for k, v in prof.items()},
+            "event_bracket_ms": round(prof["hidden_dense"].get("bracket_ms") or 0.0, 5),
+            "sum_kernel_ms_per_oil_step": round(sum(v["launches"] * v["avg_ms"] for v in prof.values() if v["avg_ms"]) / (a.steps * S), 5),
+            "wall_ms_per_oil_step": round(dt * 1e3 / (a.steps * S), 5),
         }
         if alt is not None:
             h2 = alt["prof"]["hidden_dense"]

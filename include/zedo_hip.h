@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define ZEDO_ABI_VERSION 3   /* 3: + zedo_reproj_degenerate, zedo_pose_min, zedo_weights_set_math / zedo_weights_get_math */
+#define ZEDO_ABI_VERSION 4   /* 3: + zedo_reproj_degenerate, zedo_pose_min, zedo_weights_set_math / zedo_weights_get_math;
+                              * 4: + zedo_profile_bracket_ms */
 
 #define ZEDO_OK 0
 #define ZEDO_E_BADARG (-1)      /* NULL pointer, non-positive size, unsupported dimension */
@@ -222,6 +223,12 @@ int zedo_profile_stop(double *h_total_ms, long long *h_samples, long long *h_lau
 /* Shader clock (GHz) the sampled hidden-layer launches of the last profiling session really ran at: shader cycles over
  * 100 MHz wall ticks, taken by workgroup 0 of each sampled launch around its tile.  0 if nothing was sampled. */
 double zedo_profile_shader_ghz(void);
+/* What the sampling bracket itself measures (milliseconds): the median of 15 EMPTY event pairs recorded by the last
+ * zedo_profile_stop on the stream its samples came from.  Every sampled duration contains it once; the sums returned by
+ * zedo_profile_stop are raw - subtract samples x this value for the kernels' own time (bench.py does, and checks that
+ * the per-class times of one OIL iteration then add up to no more than the wall time of an iteration).  0 if nothing
+ * was sampled. */
+double zedo_profile_bracket_ms(void);
 
 #ifdef __cplusplus
 }

@@ -113,7 +113,9 @@ def test_drivers_under_torchrun_with_four_ranks_equal_the_one_rank_run(tmp_path)
     import hashlib
     import numpy as np
     cfg = lambda n: os.path.join(ROOT, "zedo-release_amd", "configs", "optim", f"concat_pose_optimization_{n}.py")
-    pick = lambda out: sorted({l.strip() for l in out.splitlines() if l.startswith("mean ") and "MPJPE" in l})   # every rank prints them
+    import re
+    # every rank prints the two means, and four ranks' lines may interleave on one pipe: collect (name, value) pairs
+    pick = lambda out: sorted(set(re.findall(r"mean (PA-MPJPE|MPJPE) : ([0-9.eE+-]+?)(?=mean|\s|$)", out)))
     outs, shas = {}, {}
     for n in (1, 4):
         d = tmp_path / f"r{n}"

@@ -60,6 +60,15 @@ def test_bench_exchange_step_on_rccl_is_bit_identical():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert set(r) >= {"traffic", "measured_live", "replayed", "box_mfma_peak_measured", "frac_of_box_peak"}
     assert a["n_gpus"] == b["n_gpus"] == 1
+    # the line checks itself: per-class kernel times, less the calibrated cost of an empty event bracket,
+    # over all launches of an OIL iteration cannot exceed the wall time of an iteration; the dominant kernel cannot beat what
+    # this box's matrix pipe sustains
+    for l in (a, b):
+        assert 0 < l["event_bracket_ms"] < 0.02, l["event_bracket_ms"]
+        assert 0 < l["sum_kernel_ms_per_oil_step"] <= l["wall_ms_per_oil_step"], (l["sum_kernel_ms_per_oil_step"], l["wall_ms_per_oil_step"])
+        rf = l["roofline"]
+        assert rf["flop_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e12 <= rf["box_mfma_peak_measured"]
+        assert rf["avg_launch_ms"] <= rf["avg_launch_ms_bracketed"]
     assert a["selection_sha16"] == b["selection_sha16"], (a["selection_sha16"], b["selection_sha16"])
     assert a["mpjpe_best_of_H_m"] == b["mpjpe_best_of_H_m"] and a["pa_mpjpe_best_of_H_m"] == b["pa_mpjpe_best_of_H_m"]
 

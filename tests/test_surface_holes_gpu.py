@@ -145,6 +145,40 @@ def test_singular_least_squares_system_raises_like_torch_inverse(zh, weights0):
     assert bool(torch.isfinite(x_ok).all())
 
 
+def test_ray_cache_hits_for_confidences_that_need_conversion(zh):
+    """with a float64 / non-contiguous `conf` the converted copy was a new tensor on every call, so the ray cache
+    never hit and every gradient_field_gen step paid a device allocation + a stream sync.  The cache now keys on the
+    CALLER's tensors: the second call with the same objects is a hit, the clamp of conf (reference :64-66) is visible on
+    the caller's tensor, and a write to it (version counter) is a miss again."""
+    from lib.algorithms.advanced import simple_zeroshot_opt as szo
+    from lib.dataset import synthetic as syn
+    d = syn.make_poses(5, seed=8, conf_mode="wild")
+    uv, K = dev(d["db_2d"][:, :, :2]), dev(d["camera_param"])
+    x = dev(0.1 * np.random.default_rng(1).standard_normal((5, 17, 3)))
+    conf64 = torch.tensor(d["db_2d"][:, :, 2], dtype=torch.float64, device="cuda")
+    wide = torch.zeros((5, 34), dtype=torch.float32, device="cuda")
+    wide[:, ::2] = conf64.float()
+    strided = wide[:, ::2]                                   # fp32 but not contiguous
+    ref = szo.gradient_field_gen(uv, x, K, conf=dev(d["db_2d"][:, :, 2]), returnT=True)
+    for conf in (conf64, strided):
+        szo.invalidate_ray_cache()
+        calls = []
+        real = zh.reproj_prepare
+        zh.reproj_prepare = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            g1, T1 = szo.gradient_field_gen(uv, x, K, conf=conf, returnT=True)
+            assert float(conf.max()) == 1.0 and abs(float(conf.min()) - 1e-4) < 1e-9           # clamped in place
+            g2, T2 = szo.gradient_field_gen(uv, x, K, conf=conf, returnT=True)
+            assert len(calls) == 1, "second call with the same tensors must hit the cache"
+            conf[0, 0] = 0.5                                                                    # version counter moves
+            szo.gradient_field_gen(uv, x, K, conf=conf, returnT=True)
+            assert len(calls) == 2
+        finally:
+            zh.reproj_prepare = real
+        assert torch.equal(g1, g2) and torch.equal(T1, T2) and torch.equal(g1, ref[0]) and torch.equal(T1, ref[1])
+    szo.invalidate_ray_cache()
+
+
 def test_scale_by_sigma_takes_the_generic_route_and_divides_by_sigma(zh, model, weights0):
     """A subVPSDE configuration with model.scale_by_sigma = True (reference model.py:294: eps / sigmas[t]) must not be
     served by the closed-form zedo_sde_step (which knows no sigma): pc_sampler has to go through model.forward, and the

@@ -864,6 +864,14 @@ def gen_driver_pw3d_full_env():
                       perturb=run)
 
 
+def gen_driver_pw3d_full_tied():
+    """configs[2] with a CONTRACTIVE prior (syn.make_weights(prior="tied")): does the spread of the end-to-end MPJPE between
+    two fp32 implementations - the IPO's chaotic last iterate carried through an expansive loop - collapse when the denoiser
+    pulls towards an attractor, as a trained one does?  Same inputs as gen_driver_pw3d_full.  2.4 h on one thread."""
+    _driver_full_size("driver_pw3d_full_tied", 1015, 50, 1000, 103, 19, list(range(17)), 8.0, 0.2, "uniform", "3dpw", CACHE,
+                      weights=syn.make_weights(seed=0, prior="tied"))
+
+
 def gen_driver_pw3d_ipoens():
     """The reference's IPO END STATE as a distribution: the 500 Adam iterations of run/opt_main.py:180-195 on configs[2]
     (50 hypotheses x 1015 poses) for ZEDO_IPOENS_MEMBERS ulp-perturbed copies of the detections (syn.perturb_ulp streams
@@ -1002,9 +1010,9 @@ GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo
             driver_pw3d_full_b=gen_driver_pw3d_full_b, driver_pw3d_full_c=gen_driver_pw3d_full_c,
             driver_ipo_pins=gen_driver_ipo_pins, driver_pw3d_full_oil64=gen_driver_pw3d_full_oil64, driver_pw3d_full_b_oil64=gen_driver_pw3d_full_b_oil64,
             driver_pw3d_full_c_oil64=gen_driver_pw3d_full_c_oil64, driver_pw3d_full_env=gen_driver_pw3d_full_env,
-            driver_pw3d_ipoens=gen_driver_pw3d_ipoens)
+            driver_pw3d_ipoens=gen_driver_pw3d_ipoens, driver_pw3d_full_tied=gen_driver_pw3d_full_tied)
 SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64", "driver_pw3d_full_b", "driver_pw3d_full_c", "driver_ipo_pins", "driver_pw3d_full_oil64", "driver_pw3d_full_b_oil64",
-        "driver_pw3d_full_c_oil64", "driver_pw3d_full_env", "driver_pw3d_ipoens"}     # only with --only
+        "driver_pw3d_full_c_oil64", "driver_pw3d_full_env", "driver_pw3d_ipoens", "driver_pw3d_full_tied"}     # only with --only
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -6,6 +6,7 @@
 #include "../../include/zedo_hip.h"
 #include "zedo_internal.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -37,6 +38,7 @@ struct zedo_weights {
     float wmax_hid[6];          // max |w| of the four hidden layers, pre_dense, post_dense (from the host copy at create time)
     float act_bound;            // upper bound of every activation |h| the network can produce (from gamma / beta, see zedo_weights_create)
     float unscale[6];           // 2^-wshift, same order
+    bool finite16;              // no NaN / inf among the six weight matrices and the GroupNorm parameters (fmax cannot see a NaN)
 };
 
 struct zedo_schedule {
@@ -68,6 +70,8 @@ struct Prof {
     long long *d_clk = nullptr;   // [pool.size()][2]: {shader cycles, 100 MHz ticks} of workgroup 0 of a sampled hidden launch
     size_t clk_cap = 0;
     double ghz = 0.0;             // result of the last session
+    double bracket_ms = 0.0;      // result of the last session: what an EMPTY event pair on the launch stream measures
+    hipStream_t last_stream = nullptr;
     size_t used = 0;
     long long seen[ZEDO_PROF_CLASSES] = {0, 0, 0, 0};
 } g_prof;
@@ -84,6 +88,7 @@ struct ProfScope {
         if (g_prof.d_clk && g_prof.used < g_prof.clk_cap) clk = g_prof.d_clk + 2 * g_prof.used;
         pr = &g_prof.pool[g_prof.used++];
         pr->cls = cls;
+        g_prof.last_stream = st;
         (void)hipEventRecord(pr->a, st);
     }
     ~ProfScope() { if (pr) (void)hipEventRecord(pr->b, st); }
@@ -122,6 +127,7 @@ extern "C" int zedo_profile_start(int sample_every, int max_samples) {
 }
 
 extern "C" double zedo_profile_shader_ghz(void) { return g_prof.ghz; }
+extern "C" double zedo_profile_bracket_ms(void) { return g_prof.bracket_ms; }
 
 extern "C" int zedo_profile_stop(double *h_total_ms, long long *h_samples, long long *h_launches) {
     g_prof.on.store(false, std::memory_order_release);
@@ -134,6 +140,25 @@ extern "C" int zedo_profile_stop(double *h_total_ms, long long *h_samples, long 
         HIPCHK(hipEventElapsedTime(&ms, g_prof.pool[i].a, g_prof.pool[i].b));
         tot[g_prof.pool[i].cls] += ms;
         cnt[g_prof.pool[i].cls] += 1;
+    }
+    // What the bracket itself costs: the median of 15 EMPTY event pairs on the stream the samples were taken on (the
+    // samples above are synchronised, the stream is idle).  A sampled duration contains it once; zedo_profile_stop
+    // reports the raw sums, callers subtract samples x zedo_profile_bracket_ms() (bench.py does).
+    g_prof.bracket_ms = 0.0;
+    if (g_prof.used) {
+        float em[15];
+        int got = 0;
+        for (int i = 0; i < 15; ++i) {
+            if (hipEventRecord(g_prof.pool[0].a, g_prof.last_stream) != hipSuccess) break;
+            if (hipEventRecord(g_prof.pool[0].b, g_prof.last_stream) != hipSuccess) break;
+            if (hipEventSynchronize(g_prof.pool[0].b) != hipSuccess) break;
+            if (hipEventElapsedTime(&em[got], g_prof.pool[0].a, g_prof.pool[0].b) != hipSuccess) break;
+            ++got;
+        }
+        if (got) {
+            std::sort(em, em + got);
+            g_prof.bracket_ms = em[got / 2];
+        }
     }
     g_prof.ghz = 0.0;
     if (g_prof.d_clk && g_prof.used) {
@@ -209,9 +234,16 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     // |SiLU(GroupNorm(.))| <= max|gamma| sqrt(31) + max|beta| per layer (a group of 32 normalised values has |v| <= sqrt(31));
     // h = pre, then h += h2 twice: |h| <= bound[0] + bound[2] + bound[4]
     float gn_bound[NLAYER] = {0, 0, 0, 0, 0};
+    // std::fmax drops a NaN operand, so the maxima above / below cannot see one: finiteness of the six weight matrices and
+    // of every GroupNorm parameter is tracked on its own (zedo_weights_set_math refuses f16x3 when it is false)
+    bool finite = true;
+    auto all_finite = [&](const float *v, size_t n) {
+        for (size_t q = 0; q < n; ++q) finite &= (bool)std::isfinite(v[q]);
+    };
     auto gn_bound_of = [&](const float *g, const float *be, size_t n) {
         float gm = 0.f, bm = 0.f;
         for (size_t q = 0; q < n; ++q) { gm = std::fmax(gm, std::fabs(g[q])); bm = std::fmax(bm, std::fabs(be[q])); }
+        all_finite(g, n); all_finite(be, n);
         return gm * 5.5677643f + bm;     // sqrt(31)
     };
     // pre_dense
@@ -221,6 +253,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     const float *w_s = next(E * E), *b_s = next(E);
     for (size_t n = 0; n < H; ++n) memcpy(&img[o_Wpre + n * XLD], w_pre + n * J3, sizeof(float) * J3);
     for (size_t q = 0; q < H * J3; ++q) wmax_hid_tmp[4] = std::fmax(wmax_hid_tmp[4], std::fabs(w_pre[q]));
+    all_finite(w_pre, H * J3);
     memcpy(&img[o_gamma], g_pre, sizeof(float) * H);
     memcpy(&img[o_beta], be_pre, sizeof(float) * H);
     memcpy(&img[o_Ws], w_s, sizeof(float) * E * E);
@@ -233,6 +266,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
         gn_bound[l] = gn_bound_of(g, be, H);
         float wm = 0.f;
         for (size_t q = 0; q < H * H; ++q) wm = std::fmax(wm, std::fabs(w[q]));
+        all_finite(w, H * H);
         wmax_hid_tmp[l - 1] = wm;
         memcpy(&img[o_Wt + (size_t)l * H * E], wt, sizeof(float) * H * E);
         memcpy(&img[o_gamma + (size_t)l * H], g, sizeof(float) * H);
@@ -244,6 +278,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     const float *w_post = next((size_t)J3 * H), *b_post = next(J3);
     memcpy(&img[o_Wpost], w_post, sizeof(float) * J3 * H);
     for (size_t q = 0; q < (size_t)J3 * H; ++q) wmax_hid_tmp[5] = std::fmax(wmax_hid_tmp[5], std::fabs(w_post[q]));
+    all_finite(w_post, (size_t)J3 * H);
     memcpy(&img[o_bpost], b_post, sizeof(float) * J3);
 
     zedo_weights *w = new (std::nothrow) zedo_weights();
@@ -253,6 +288,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     w->math = ZEDO_MATH_F32; w->d_W16 = nullptr;
     for (int l = 0; l < 6; ++l) { w->wmax_hid[l] = wmax_hid_tmp[l]; w->unscale[l] = 1.0f; }
     w->act_bound = std::fmax(std::fmax(gn_bound[1], gn_bound[3]), gn_bound[0] + gn_bound[2] + gn_bound[4]);
+    w->finite16 = finite;
     hipError_t e = hipMalloc(&w->d_all, off * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&w->d_scratch, sizeof(float) * ((size_t)2 * ROW_PAD * EMB + ROW_PAD));
     if (e != hipSuccess) { (void)hipFree(w->d_all); delete w; return (int)e; }
@@ -286,8 +322,9 @@ extern "C" int zedo_weights_set_math(zedo_weights_t *w, int mode, void *stream) 
     if (!w || (mode != ZEDO_MATH_F32 && mode != ZEDO_MATH_F16X3)) return ZEDO_E_BADARG;
     if (mode == ZEDO_MATH_F16X3 && !w->d_W16) {
         hipStream_t st = (hipStream_t)stream;
+        if (!w->finite16) return ZEDO_E_BADARG;      // a NaN / inf weight or GroupNorm parameter has no fp16 image
         for (int l = 0; l < 6; ++l)
-            if (!std::isfinite(w->wmax_hid[l])) return ZEDO_E_BADARG;          // a non-finite weight has no fp16 image
+            if (!std::isfinite(w->wmax_hid[l])) return ZEDO_E_BADARG;
         // activations are stored as UNSCALED fp16 pieces: refuse the mode for a network whose GroupNorm parameters allow an
         // activation near the fp16 range (65504) instead of overflowing silently (trained checkpoints: O(10))
         if (!(w->act_bound < 32768.0f)) return ZEDO_E_BADARG;
@@ -502,6 +539,7 @@ static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad
     if (e != hipSuccess) return e;
     a.X = h; a.ldx = HID; a.W = w->W_post; a.ldw = HID; a.K = HID; a.N = XLD; a.bias = w->b_post;
     a.gamma = a.beta = nullptr; a.ldo = XLD;
+    a.scratch = h1 + (size_t)Bp * XLD;      // h1 is free here ([Bp][XLD] of it may hold eps_out): K-quarter sums of small batches
     ProfScope ps(ZEDO_PROF_POST, st);
     if (sde) {
         a.out = xpad; a.sde_a = sa; a.sde_c = sc;

@@ -76,8 +76,12 @@ __device__ long long *g_timeline = nullptr;   // ubench only: 8 x int64 per work
 // KSKIP (K == NBUF * BK only, i.e. the ring holds all of K): the last KSKIP fragment groups (8 k each) of the last
 // tile are known to be zero in both operands and their MFMAs are not issued - pre_dense: K = 51 padded to 64, the
 // group k = 56..63 is padding on both sides; skipping exact zeros leaves every sum bit-identical.
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int KSKIP = 0>
-__device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, const int n0) {
+// KQ > 1 (post_dense): the K loop is cut into KQ equal parts, each summed as its own fma chain from zero and the parts
+// combined left to right - ((q0 + q1) + q2) + q3 - the order the split launch of small batches produces (EPI_PARTIAL
+// tiles + post_reduce_kernel), so that a row's result does not depend on the launch shape.
+// out_m0: row of a.out the tile's first row is written to (== m0 except for EPI_PARTIAL tiles, which write quarter sums).
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int KSKIP = 0, int KQ = 1>
+__device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, const int n0, const int out_m0) {
     constexpr int NW = WM * WN;
     constexpr int CPR = BK / 4;                         // 16-byte chunks per tile row (8 or 4)
     constexpr int RPD = 64 / CPR;                       // tile rows moved by one DMA instruction (8 or 16)
@@ -194,7 +198,7 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
     // (s_setprio around prologue / epilogue was measured: no effect - their starvation behind the partner's
     //  pending MFMAs is structural, not a priority matter.)
     // epilogue parameters -> LDS once (LDS reads are free next to MFMAs, VMEM loads are not)
-    if (tid < BN / 4) {
+    if (EPI != EPI_PARTIAL && tid < BN / 4) {
         *reinterpret_cast<f32x4 *>(Ps + tid * 4) = *reinterpret_cast<const f32x4 *>(a.bias + n0 + tid * 4);
         if constexpr (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) {
             *reinterpret_cast<f32x4 *>(Ps + BN + tid * 4) = *reinterpret_cast<const f32x4 *>(a.gamma + n0 + tid * 4);
@@ -202,6 +206,8 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
         }
     }
     const int KT = a.K / BK;
+    f32x16 qsum[KQ > 1 ? TI : 1][KQ > 1 ? TJ : 1];       // KQ > 1: ((q0 + q1) + q2) + ... so far
+    const int KTQ = KT / KQ;                              // tiles per part (a multiple of NBUF: checked at launch)
 #pragma unroll
     for (int t = 0; t < NBUF; ++t) dma(min(t, KT - 1), t);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * IPW) : "memory");   // tile 0 landed
@@ -272,6 +278,27 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
             if constexpr (SCHED & 1) __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if constexpr (KQ > 1) {
+          // every MFMA of tiles kt0 .. kt0 + NBUF - 1 is issued, none of the next tile: a part ends exactly here
+          if ((kt0 + NBUF) % KTQ == 0) {
+              const bool first = (kt0 + NBUF == KTQ);
+#pragma unroll
+              for (int i = 0; i < TI; ++i)
+#pragma unroll
+                  for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                      for (int e = 0; e < 16; ++e) {
+                          qsum[i][j][e] = first ? acc[i][j][e] : qsum[i][j][e] + acc[i][j][e];
+                          acc[i][j][e] = 0.0f;
+                      }
+          }
+      }
+    }
+    if constexpr (KQ > 1) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = qsum[i][j];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // drain the trailing (unused) DMA before any wave of the workgroup may exit
@@ -301,7 +328,7 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
         static_assert(SR * BN == STAGE_F, "stage size");
         constexpr bool HAS_RES = (EPI == EPI_GN_SILU_RES || EPI == EPI_SDE);
         float *S = smem;
-        float *obase = a.out + (size_t)m0 * a.ldo + n0;
+        float *obase = a.out + (size_t)out_m0 * a.ldo + n0;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             if constexpr (HAS_RES) {
@@ -413,25 +440,35 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
 }
 
 // One tile per workgroup: block index -> tile.
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int KSKIP = 0>
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int KSKIP = 0, int KQ = 1>
 __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, const int nwg) {
     // XCD-aware, bijective block -> tile map: the hardware places block b on XCD b % 8; give every
     // XCD a contiguous range of tiles so that the column tiles of one row tile share one L2.
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int ncol = a.N / BN;
+    if constexpr (EPI == EPI_PARTIAL) {
+        // one K quarter per workgroup: block lid -> (row tile lid / 4, quarter lid % 4); a.K is the quarter's depth;
+        // the quarter sums of a row tile land next to each other in a.out = [tile][quarter][BM][BN]
+        LayerArgs b = a;
+        const int tile = lid >> 2, q = lid & 3;
+        b.X = a.X + (size_t)q * a.K;
+        b.W = a.W + (size_t)q * a.K;
+        layer_tile<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP, 1>(b, tile * BM, 0, lid * BM);
+        return;
+    }
 #if defined(ZEDO_EXP_MAP) && ZEDO_EXP_MAP == 1
     // experiment (tools/traffic_clock_experiment.sh): the naive map - column tile = block % ncol, so with 8 column tiles
     // every XCD owns ONE column tile of W and every row tile of X is fetched by all 8 XCDs
-    layer_tile<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP>(a, (bid / ncol) * BM, (bid % ncol) * BN);
+    layer_tile<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP, KQ>(a, (bid / ncol) * BM, (bid % ncol) * BN, (bid / ncol) * BM);
 #else
-    layer_tile<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP>(a, (lid / ncol) * BM, (lid % ncol) * BN);
+    layer_tile<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP, KQ>(a, (lid / ncol) * BM, (lid % ncol) * BN, (lid / ncol) * BM);
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1, int KSKIP = 0>
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1, int KSKIP = 0, int KQ = 1>
 __global__ __launch_bounds__(WM *WN * 64, WPE) void layer_kernel(LayerArgs a) {
-    layer_body<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP>(a, blockIdx.x, gridDim.x);
+    layer_body<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP, KQ>(a, blockIdx.x, gridDim.x);
 }
 
 // One launch, two tile shapes: workgroups [0, nbig) run 128x128 tiles on the rows that fill whole rounds of the
@@ -501,24 +538,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? (ZEDO_PAIR_RES_BK == 16 ? 6 : 
     if (probe) { big.clk[0] = clock64() - c0; big.clk[1] = wall_clock64() - w0; }
 }
 
-// Per-device launch state.  The dense kernels ask for 67-83 KB of dynamic LDS (above the 64 KB default), which must
-// be allowed once per kernel AND per device; the flags are idempotent (a race sets the attribute twice).
-constexpr int MAX_DEVICES = 16;
-static int current_device() {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    return (dev >= 0 && dev < MAX_DEVICES) ? dev : 0;
-}
-static hipError_t allow_lds(const void *kern, size_t lds, std::atomic<bool> *done) {
-    const int dev = current_device();
-    if (!done[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        done[dev].store(true, std::memory_order_release);
-    }
-    return hipSuccess;
-}
-static int num_cus();
+// (per-device launch state: allow_lds / num_cus of zedo_internal.h)
 
 template <int EPI, int W8>
 static hipError_t launch_pair(const LayerArgs &big, const LayerArgs &small, hipStream_t st) {
@@ -536,30 +556,18 @@ static hipError_t launch_pair(const LayerArgs &big, const LayerArgs &small, hipS
     return hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1, int KSKIP = 0>
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1, int KSKIP = 0, int KQ = 1>
 static hipError_t launch_cfg(const LayerArgs &a, hipStream_t st) {
     constexpr size_t ring_f = (size_t)NBUF * (BM + BN) * BK, stage_f = (size_t)WM * 32 * BN;
     constexpr size_t lds = ((ring_f > stage_f ? ring_f : stage_f) + 3 * BN) * sizeof(float);
-    if (a.Mp <= 0 || a.Mp % BM || a.N % BN || a.K % (BK * NBUF)) return hipErrorInvalidValue;
+    if (a.Mp <= 0 || a.Mp % BM || a.N % BN || a.K % (BK * NBUF * KQ)) return hipErrorInvalidValue;
     if (KSKIP && a.K != BK * NBUF) return hipErrorInvalidValue;
-    auto kern = layer_kernel<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, WPE, KSKIP>;
+    auto kern = layer_kernel<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, WPE, KSKIP, KQ>;
     static std::atomic<bool> attr_done[MAX_DEVICES];      // per instantiation and per device
     if (hipError_t e = allow_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
-    const int nwg = (a.Mp / BM) * (a.N / BN);
+    const int nwg = (a.Mp / BM) * (a.N / BN) * (EPI == EPI_PARTIAL ? 4 : 1);
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(WM * WN * 64), lds, st, a);
     return hipGetLastError();
-}
-
-static int num_cus() {
-    static std::atomic<int> n[MAX_DEVICES];
-    const int dev = current_device();
-    int v = n[dev].load(std::memory_order_relaxed);
-    if (!v) {
-        hipDeviceProp_t p;
-        v = (hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
-        n[dev].store(v, std::memory_order_relaxed);
-    }
-    return v;
 }
 
 static LayerArgs rows_of(const LayerArgs &a, int row0, int rows) {
@@ -607,13 +615,37 @@ static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
         return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);
     }
     constexpr int WG_PER_CU = (EPI == EPI_GN_SILU_RES ? ZEDO_PAIR_RES_BK : ZEDO_PAIR_PLAIN_BK) == 32 ? 2 : (EPI == EPI_GN_SILU_RES ? 3 : ZEDO_PAIR_PLAIN_WGS);
+    constexpr int W8 = (EPI == EPI_GN_SILU_RES) ? ZEDO_PAIR_W8_RES : ZEDO_PAIR_W8_PLAIN;
     const int per_round = num_cus() * WG_PER_CU * 128 / (a.N / 128);      // rows covered by one full round of 128x128 tiles
-    const int rows_big = (a.Mp / per_round) * per_round;
-    const int rows_small = a.Mp - rows_big;                       // multiple of 64 (BATCH_PAD)
+    int rows_big = (a.Mp / per_round) * per_round;
     static const bool split_launch = getenv("ZEDO_SPLIT_REMAINDER") != nullptr;   // A/B knob: remainder as its own launch
+    static const bool no_mid_mix = getenv("ZEDO_NO_MID_MIX") != nullptr;          // A/B knob: round-3 policy below one round
+    if (rows_big == 0 && !split_launch && !no_mid_mix) {
+        // Less than one round of resident workgroups (mid-size batches, strong-scaling shards): a single tile shape
+        // quantises badly - 6 400 rows are 400 128x128 tiles on 256 CUs, i.e. two tiles on 144 CUs and one on the rest
+        // (124 us where 85 would do).  Instead: 128x128 tiles on as many rows as give every CU the SAME number of them
+        // (whole multiples of one tile per CU), the rest as small tiles dispatched last in the same launch, which spread
+        // 2-3 per CU behind the big ones.  Estimated with the tile times of launch_small; taken when it beats the best
+        // single shape.  (Bit-identical either way: every tile shape issues the same products in the same order.)
+        const int one_each = num_cus() * 128 / (a.N / 128);               // rows that put one 128x128 tile on every CU
+        const int mix_big = (a.Mp / one_each) * one_each;
+        constexpr int SMR = (W8 ? 64 : 32);
+        if (mix_big > 0 && a.Mp > mix_big && (a.Mp - mix_big) % SMR == 0) {
+            const double kd = a.K / 1024.0;
+            const long small_tiles = (long)((a.Mp - mix_big) / SMR) * (a.N / 128);
+            const double est_mix = (mix_big / one_each) * 55.1 * kd + (double)((small_tiles + num_cus() - 1) / num_cus()) * (W8 ? 28.2 : 14.5) * kd + 6.0;
+            auto single = [&](int bm, int slots, double t) {
+                if (a.Mp % bm) return 1e30;
+                const long tiles = (long)(a.Mp / bm) * (a.N / 128);
+                return (double)((tiles + (long)num_cus() * slots - 1) / ((long)num_cus() * slots)) * 6.0 + (double)((tiles + num_cus() - 1) / num_cus()) * t * kd;
+            };
+            const double est_single = fmin(fmin(single(32, 3, 14.5), single(64, 3, 28.2)), single(128, 2, 55.1));
+            if (est_mix < est_single) rows_big = mix_big;
+        }
+    }
+    const int rows_small = a.Mp - rows_big;                       // multiple of 64 (BATCH_PAD)
     if (rows_small > 0 && rows_big > 0 && !split_launch) {
         // eight-wave workgroups bring 64-row remainder tiles along; a short remainder finishes sooner as 32-row tiles
-        constexpr int W8 = (EPI == EPI_GN_SILU_RES) ? ZEDO_PAIR_W8_RES : ZEDO_PAIR_W8_PLAIN;
         if (W8 && rows_small >= 1536) return launch_pair<EPI, W8>(rows_of(a, 0, rows_big), rows_of(a, rows_big, rows_small), st);
         return launch_pair<EPI, 0>(rows_of(a, 0, rows_big), rows_of(a, rows_big, rows_small), st);
     }
@@ -630,10 +662,25 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
     if (a.N == XLD) {  // post_dense: 51 (padded to 64) output channels, one column tile
         // bandwidth bound (reads the 4 KB activation row once): 64-row tiles, two workgroups per CU, 4-deep ring
         // (measured 70.6 us vs 75.7 us for 128-row tiles and 88 us for 32-row tiles at 50 750 rows)
+        // K is summed as four quarter chains combined left to right in EVERY shape (LayerArgs::scratch): up to
+        // POST_SPLIT_ROWS rows one workgroup per (32-row tile, quarter) + post_reduce_kernel - a 32x64 tile is a 512-MFMA
+        // dependent chain on 2 of a CU's 4 SIMDs, 18.9 us whatever the batch; four 128-MFMA chains on 4x the CUs take a
+        // third of that - above it the quarters are folded inside one 64x64 tile (the chip is full there).
+        static const bool no_split = getenv("ZEDO_POST_NO_SPLIT") != nullptr;      // A/B knob: the folded tile for every size
+        if (epilogue != EPI_SDE && epilogue != EPI_BIAS) return hipErrorInvalidValue;
+        if (a.K % (4 * 32 * 4)) return hipErrorInvalidValue;
+        if (a.Mp <= POST_SPLIT_ROWS && a.Mp % 32 == 0 && a.scratch && !no_split) {
+            LayerArgs p = a;
+            p.K = a.K / 4; p.out = a.scratch; p.ldo = XLD;
+            if (hipError_t e = launch_cfg<32, 64, 1, 2, EPI_PARTIAL, 4, 0, 32, SCHED_THIN>(p, st); e != hipSuccess) return e;
+            const bool sde = epilogue == EPI_SDE;
+            return launch_post_reduce(sde ? a.out : nullptr, a.scratch, a.bias, a.sde_a, a.sde_c, sde ? 1 : 0, sde ? nullptr : a.out,
+                                      sde ? a.rp_geom : nullptr, a.rp_T, a.rp_solve, a.rp_B, a.Mp, a.rp_N, a.rp_row0, st);
+        }
         const bool small = a.Mp <= 8192 && a.Mp % 32 == 0;
         switch (epilogue) {
-            case EPI_SDE: return small ? launch_cfg<32, 64, 1, 2, EPI_SDE, 4, 0, 32, SCHED_THIN>(a, st) : launch_cfg<64, 64, 2, 2, EPI_SDE, 4, 0, 32, SCHED_THIN>(a, st);
-            case EPI_BIAS: return small ? launch_cfg<32, 64, 1, 2, EPI_BIAS, 4, 0, 32, SCHED_THIN>(a, st) : launch_cfg<64, 64, 2, 2, EPI_BIAS, 4, 0, 32, SCHED_THIN>(a, st);
+            case EPI_SDE: return small ? launch_cfg<32, 64, 1, 2, EPI_SDE, 4, 0, 32, SCHED_THIN, 1, 0, 4>(a, st) : launch_cfg<64, 64, 2, 2, EPI_SDE, 4, 0, 32, SCHED_THIN, 1, 0, 4>(a, st);
+            case EPI_BIAS: return small ? launch_cfg<32, 64, 1, 2, EPI_BIAS, 4, 0, 32, SCHED_THIN, 1, 0, 4>(a, st) : launch_cfg<64, 64, 2, 2, EPI_BIAS, 4, 0, 32, SCHED_THIN, 1, 0, 4>(a, st);
         }
         return hipErrorInvalidValue;
     }

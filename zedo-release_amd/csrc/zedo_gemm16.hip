@@ -439,18 +439,11 @@ __global__ __launch_bounds__(256, 4) void layer16_small_kernel(Layer16Args a) {
     layer16_body<64, 64, 2, 2, EPI, 4, 0>(a, blockIdx.x, gridDim.x);
 }
 
-constexpr int MAX_DEVICES16 = 16;
+constexpr int MAX_DEVICES16 = MAX_DEVICES;      // per-device launch state: allow_lds / num_cus of zedo_internal.h
 
 template <class K>
 static hipError_t launch_thin16(K kern, std::atomic<bool> *attr_done, size_t lds, int grid, const Layer16Args &a, hipStream_t st) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= MAX_DEVICES16) dev = 0;
-    if (!attr_done[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done[dev].store(true, std::memory_order_release);
-    }
+    if (hipError_t e = allow_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
     return hipGetLastError();
 }
@@ -464,14 +457,7 @@ static hipError_t launch_pair16(const Layer16Args &big, const Layer16Args &small
     constexpr size_t lds = lds_big > lds_small ? lds_big : lds_small;      // each tile shape finds its parameter block behind ITS body
     auto kern = layer16_pair_kernel<EPI, BIG_N>;
     static std::atomic<bool> attr_done[MAX_DEVICES16];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= MAX_DEVICES16) dev = 0;
-    if (!attr_done[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done[dev].store(true, std::memory_order_release);
-    }
+    if (hipError_t e = allow_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const int nbig = (big.Mp / BIG_M) * (big.N / BIG_N), nsmall = (small.Mp / 64) * (small.N / 64);
     if (nbig + nsmall == 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(nbig + nsmall), dim3(256), lds, st, big, small, nbig);
@@ -523,15 +509,7 @@ hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st) {
         }
         return hipErrorInvalidValue;
     }
-    static std::atomic<int> cus_cached{0};
-    int cus = cus_cached.load(std::memory_order_relaxed);
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        (void)hipGetDevice(&dev);
-        cus = (hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
-        cus_cached.store(cus, std::memory_order_relaxed);
-    }
+    const int cus = num_cus();            // of the CURRENT device (cached per device)
     // big tiles on the rows that fill whole rounds of 2 workgroups per CU; the remainder (and every batch smaller than
     // one round) on 64x64 tiles: finer tiles spread a short launch over more CUs
     // Which rows get which tile (cycles of a CU: a 128x256 tile ~74k alone, a 128x128 tile ~41k, a 64x64 tile ~14.5k):

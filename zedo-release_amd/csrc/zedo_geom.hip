@@ -4,6 +4,8 @@
 // global traffic is coalesced through LDS tiles, each lane then owns one pose row.
 #include "zedo_internal.h"
 
+#include <atomic>
+
 namespace zedo {
 
 // f32x4, GEOM_F and reproj_row<J>: zedo_internal.h
@@ -203,6 +205,91 @@ __global__ __launch_bounds__(64) void reproj_step_kernel(float *__restrict__ xpa
     }
 }
 
+// Second half of post_dense on small batches (zedo_gemm.hip, EPI_PARTIAL): the four K-quarter sums of every row are
+// combined in the one order every launch shape uses - ((q0 + q1) + q2) + q3 - then bias, then either the SDE update of
+// the padded state (x' = a x + c eps: "o = acc + b; o *= c; x' = fma(a, x, o)", the statements of the fused epilogue) or
+// eps itself, then - geom given - the reprojection correction of the next iteration, one lane per row like
+// reproj_step_kernel.  64 rows per workgroup; the state tile moves through LDS as coalesced 16-byte accesses.
+template <int J>
+__global__ __launch_bounds__(64) void post_reduce_kernel(float *__restrict__ xpad, const float *__restrict__ partial,
+                                                         const float *__restrict__ bias, float sde_a, float sde_c, int sde,
+                                                         float *__restrict__ eps_out, const float *__restrict__ geom,
+                                                         float *__restrict__ T, int solve, int B, int N, long long row_offset) {
+    constexpr int D = J * 3, R = BATCH_PAD, LD = XLD + 4, NV = (D + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float sx[R * LD];
+    __shared__ __attribute__((aligned(16))) float sb[XLD];
+    const int row0 = blockIdx.x * R, tid = threadIdx.x;
+    float *base = (sde ? xpad : eps_out) + (size_t)row0 * XLD;  // Bp is a multiple of BATCH_PAD: the whole tile exists
+    sb[tid] = bias[tid];
+    if (sde) {
+#pragma unroll
+        for (int it = 0; it < XLD / 4; ++it) {
+            const int idx = it * R + tid, r = idx >> 4, c4 = idx & 15;
+            *reinterpret_cast<f32x4 *>(sx + r * LD + c4 * 4) = *reinterpret_cast<const f32x4 *>(base + (size_t)idx * 4);
+        }
+    }
+    __syncthreads();
+    const int b = row0 + tid;
+    {
+        // quarter sums of row b: partial[(b / 32) * 4 + q][b % 32][64]
+        const float *p0 = partial + ((size_t)(b >> 5) * 4 * 32 + (b & 31)) * XLD;
+        float *xr = sx + tid * LD;
+#pragma unroll
+        for (int v = 0; v < XLD / 4; ++v) {
+            const f32x4 q0 = *reinterpret_cast<const f32x4 *>(p0 + v * 4);
+            const f32x4 q1 = *reinterpret_cast<const f32x4 *>(p0 + 32 * XLD + v * 4);
+            const f32x4 q2 = *reinterpret_cast<const f32x4 *>(p0 + 2 * 32 * XLD + v * 4);
+            const f32x4 q3 = *reinterpret_cast<const f32x4 *>(p0 + 3 * 32 * XLD + v * 4);
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(sb + v * 4);
+            f32x4 x4 = {0.f, 0.f, 0.f, 0.f};
+            if (sde) x4 = *reinterpret_cast<const f32x4 *>(xr + v * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = ((q0[e] + q1[e]) + q2[e]) + q3[e];
+                t = t + bb[e];
+                if (sde) { t = t * sde_c; t = __builtin_fmaf(sde_a, x4[e], t); }
+                o[e] = t;
+            }
+            *reinterpret_cast<f32x4 *>(xr + v * 4) = o;
+        }
+    }
+    if (geom != nullptr && b < B) {
+        float xr[NV * 4], gr[D], Tr[3];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(sx + tid * LD + v * 4);
+            xr[4 * v] = t[0]; xr[4 * v + 1] = t[1]; xr[4 * v + 2] = t[2]; xr[4 * v + 3] = t[3];
+        }
+        Tr[0] = T[(size_t)b * 3]; Tr[1] = T[(size_t)b * 3 + 1]; Tr[2] = T[(size_t)b * 3 + 2];
+        const int n = (int)((row_offset + b) % N);
+        reproj_row<J>(xr, geom + (size_t)n * J * GEOM_F, Tr, solve != 0, gr);
+        if (solve) { T[(size_t)b * 3] = Tr[0]; T[(size_t)b * 3 + 1] = Tr[1]; T[(size_t)b * 3 + 2] = Tr[2]; }
+#pragma unroll
+        for (int c = 0; c < D; ++c) xr[c] += gr[c];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            f32x4 t = {xr[4 * v], xr[4 * v + 1], xr[4 * v + 2], xr[4 * v + 3]};
+            *reinterpret_cast<f32x4 *>(sx + tid * LD + v * 4) = t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < XLD / 4; ++it) {
+        const int idx = it * R + tid, r = idx >> 4, c4 = idx & 15;
+        *reinterpret_cast<f32x4 *>(base + (size_t)idx * 4) = *reinterpret_cast<const f32x4 *>(sx + r * LD + c4 * 4);
+    }
+}
+
+hipError_t launch_post_reduce(float *xpad, const float *partial, const float *bias, float sde_a, float sde_c, int sde,
+                              float *eps_out, const float *geom, float *T, int solve_T, int B, int Bp, int N, long long row0,
+                              hipStream_t st) {
+    if (Bp % BATCH_PAD || !partial || !bias || (sde ? !xpad : !eps_out)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(post_reduce_kernel<17>, dim3(Bp / BATCH_PAD), dim3(BATCH_PAD), 0, st, xpad, partial, bias, sde_a, sde_c, sde,
+                       eps_out, geom, T, solve_T, B, N > 0 ? N : 1, row0);
+    return hipGetLastError();
+}
+
 hipError_t launch_reproj_step_padded(float *xpad, const float *geom, float *T, int solve_T, int B, int N,
                                      long long row0, hipStream_t st) {
     hipLaunchKernelGGL(reproj_step_kernel<17>, dim3((B + BATCH_PAD - 1) / BATCH_PAD), dim3(BATCH_PAD), 0, st, xpad, geom, T,
@@ -252,33 +339,62 @@ struct AdamP {
 
 __device__ __forceinline__ float sgnf(float e) { return (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f); }
 
-constexpr int IPO_TB = 128;
 constexpr int IPO_KMAX = 17;
+constexpr int IPO_TABLE = 2048;      // Adam bias-correction terms of the first IPO_TABLE iterations (the reference runs 500)
 
 struct IpoKeys { int j[IPO_KMAX]; };   // IPO_keylist travels as a kernel argument: no device buffer, no sync
 
-__global__ __launch_bounds__(IPO_TB) void ipo_kernel(const float *__restrict__ x0, const float *__restrict__ uv,
-                                                     const float *__restrict__ Kmat, const IpoKeys keylist,
-                                                     int k, int axes_mask, float ipo_T, float min_s, float max_s,
-                                                     int iters, float inv_norm, float *__restrict__ Rout,
-                                                     float *__restrict__ Tout, float *__restrict__ qout,
-                                                     float *__restrict__ sout, float *__restrict__ state,
-                                                     int it_begin, double b1p0, double b2p0, int B, int N, int J,
-                                                     long long row_offset) {
-    __shared__ float s_cu[IPO_KMAX][IPO_TB], s_cv[IPO_KMAX][IPO_TB];
-    __shared__ int s_kl[IPO_KMAX];
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x * IPO_TB + tid;
-    if (tid < k) s_kl[tid] = keylist.j[tid];
+// step_size = lr / (1 - beta1^t) and sqrt(1 - beta2^t) of torch.optim.Adam for t = 1 .. IPO_TABLE, formed on the host by
+// the statements the kernel itself uses beyond the table (running double products, one division, one square root:
+// correctly rounded on both sides, so the table changes no bit) - two double-precision long-latency operations per
+// iteration that every lane of the fit would otherwise repeat.
+__constant__ float c_adam_step[IPO_TABLE];
+__constant__ float c_adam_bc2s[IPO_TABLE];
+
+// Sum over the 32 lanes of a half-wave in ONE fixed order, the xor butterfly 16, 8, 4, 2, 1 (ds_swizzle in bit-mask mode:
+// a cross-lane move inside 32-lane groups that touches no LDS memory).  Addition commutes, so both partners of a pair
+// form the same bits and all 32 lanes end with the same value: the optimiser state stays replicated without a broadcast.
+template <int M>
+__device__ __forceinline__ float swz_xor(float v) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (M << 10) | 0x1F));
+}
+__device__ __forceinline__ float half_sum(float v) {
+    v = v + swz_xor<16>(v);
+    v = v + swz_xor<8>(v);
+    v = v + swz_xor<4>(v);
+    v = v + swz_xor<2>(v);
+    v = v + swz_xor<1>(v);
+    return v;
+}
+
+// One pose-hypothesis row per 32-lane HALF-WAVE, one key joint per lane (k <= 17 of the 32 lanes carry a joint, the
+// others contribute exact zeros): an iteration is one joint's forward / backward (~190 instructions with its six IEEE
+// divisions) + ten half-wave sums + the Adam update, instead of k joints in sequence on one lane - the 500-iteration
+// chain of the reference's 17-joint 3DPW key list shortens ~8x (3.2 ms -> 0.4 ms for any batch that does not fill the
+// chip; a full 50 750-row batch, 0.1 % of whose pass is this kernel, runs it throughput-bound at about the old cost).
+// The sums over joints have ONE order (half_sum) whatever the batch, shard or launch: rows are bit-identical across them.
+__global__ __launch_bounds__(64) void ipo_kernel(const float *__restrict__ x0, const float *__restrict__ uv,
+                                                  const float *__restrict__ Kmat, const IpoKeys keylist,
+                                                  int k, int axes_mask, float ipo_T, float min_s, float max_s,
+                                                  int iters, float inv_norm, float *__restrict__ Rout,
+                                                  float *__restrict__ Tout, float *__restrict__ qout,
+                                                  float *__restrict__ sout, float *__restrict__ state,
+                                                  int it_begin, double b1p0, double b2p0, int B, int N, int J,
+                                                  long long row_offset) {
+    __shared__ int s_kl[32];
+    const int lane = threadIdx.x, jl = lane & 31;
+    if (lane < 32) s_kl[lane] = lane < k ? keylist.j[lane] : keylist.j[0];
     __syncthreads();
-    if (b >= B) return;
+    const int b_raw = blockIdx.x * 2 + (lane >> 5);
+    const bool row_ok = b_raw < B;
+    const int b = row_ok ? b_raw : B - 1;     // a half-wave without a row shadows the last row (uniform control flow) and stores nothing
+    const bool jact = jl < k;
     const long long gb = row_offset + b;
     const int n = (int)(gb % N), h = (int)(gb / N);
-    const float *xh = x0 + (size_t)h * J * 3;
-    for (int jj = 0; jj < k; ++jj) {
-        s_cu[jj][tid] = uv[((size_t)n * J + s_kl[jj]) * 2];
-        s_cv[jj][tid] = uv[((size_t)n * J + s_kl[jj]) * 2 + 1];
-    }
+    const int jn = s_kl[jl];
+    const float *xh = x0 + ((size_t)h * J + jn) * 3;
+    const float x = jact ? xh[0] : 0.f, y = jact ? xh[1] : 0.f, z = jact ? xh[2] : 0.f;
+    const float cu = uv[((size_t)n * J + jn) * 2], cv = uv[((size_t)n * J + jn) * 2 + 1];
     float K[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) K[i] = Kmat[(size_t)n * 9 + i];
@@ -313,28 +429,25 @@ __global__ __launch_bounds__(IPO_TB) void ipo_kernel(const float *__restrict__ x
         const float R20 = ts * (i * kk - j * r), R21 = ts * (j * kk + i * r), R22 = 1.f - ts * (i * i + j * j);
         const float scc = fminf(fmaxf(sc.p, min_s), max_s);
         const float Tx = T0[0] * scc, Ty = T0[1] * scc, Tz = T0[2] * scc;
-        float G00 = 0, G01 = 0, G02 = 0, G10 = 0, G11 = 0, G12 = 0, G20 = 0, G21 = 0, G22 = 0, gsc = 0;
-        for (int jj = 0; jj < k; ++jj) {
-            const int jn = s_kl[jj];
-            const float x = xh[jn * 3], y = xh[jn * 3 + 1], z = xh[jn * 3 + 2];
-            const float px = R00 * x + R01 * y + R02 * z + Tx;
-            const float py = R10 * x + R11 * y + R12 * z + Ty;
-            const float pz = R20 * x + R21 * y + R22 * z + Tz;
-            const float w0 = K[0] * px + K[1] * py + K[2] * pz;
-            const float w1 = K[3] * px + K[4] * py + K[5] * pz;
-            const float w2 = K[6] * px + K[7] * py + K[8] * pz;
-            const float gu = sgnf(w0 / w2 - s_cu[jj][tid]) * inv_norm;   // d mean|e| / du
-            const float gv = sgnf(w1 / w2 - s_cv[jj][tid]) * inv_norm;
-            const float gw0 = gu / w2, gw1 = gv / w2;
-            const float gw2 = -gu * ((w0 / w2) / w2) - gv * ((w1 / w2) / w2);  // torch div backward form
-            const float gpx = K[0] * gw0 + K[3] * gw1 + K[6] * gw2;       // K^T g_w
-            const float gpy = K[1] * gw0 + K[4] * gw1 + K[7] * gw2;
-            const float gpz = K[2] * gw0 + K[5] * gw1 + K[8] * gw2;
-            gsc += gpx * T0[0] + gpy * T0[1] + gpz * T0[2];
-            G00 += gpx * x; G01 += gpx * y; G02 += gpx * z;
-            G10 += gpy * x; G11 += gpy * y; G12 += gpy * z;
-            G20 += gpz * x; G21 += gpz * y; G22 += gpz * z;
-        }
+        // this lane's joint: forward, L1 sign, backward to the camera-frame point (lanes without a joint: exact zeros)
+        const float px = R00 * x + R01 * y + R02 * z + Tx;
+        const float py = R10 * x + R11 * y + R12 * z + Ty;
+        const float pz = R20 * x + R21 * y + R22 * z + Tz;
+        const float w0 = K[0] * px + K[1] * py + K[2] * pz;
+        const float w1 = K[3] * px + K[4] * py + K[5] * pz;
+        const float w2 = K[6] * px + K[7] * py + K[8] * pz;
+        const float gu = sgnf(w0 / w2 - cu) * inv_norm;   // d mean|e| / du
+        const float gv = sgnf(w1 / w2 - cv) * inv_norm;
+        const float gw0 = gu / w2, gw1 = gv / w2;
+        const float gw2 = -gu * ((w0 / w2) / w2) - gv * ((w1 / w2) / w2);  // torch div backward form
+        float gpx = K[0] * gw0 + K[3] * gw1 + K[6] * gw2;       // K^T g_w
+        float gpy = K[1] * gw0 + K[4] * gw1 + K[7] * gw2;
+        float gpz = K[2] * gw0 + K[5] * gw1 + K[8] * gw2;
+        if (!jact) { gpx = 0.f; gpy = 0.f; gpz = 0.f; }
+        const float gsc = half_sum(gpx * T0[0] + gpy * T0[1] + gpz * T0[2]);
+        const float G00 = half_sum(gpx * x), G01 = half_sum(gpx * y), G02 = half_sum(gpx * z);
+        const float G10 = half_sum(gpy * x), G11 = half_sum(gpy * y), G12 = half_sum(gpy * z);
+        const float G20 = half_sum(gpz * x), G21 = half_sum(gpz * y), G22 = half_sum(gpz * z);
         // dL/d two_s = <G, Q>
         const float gts = G00 * -(j * j + kk * kk) + G01 * (i * j - kk * r) + G02 * (i * kk + j * r) +
                           G10 * (i * j + kk * r) + G11 * -(i * i + kk * kk) + G12 * (j * kk - i * r) +
@@ -346,15 +459,17 @@ __global__ __launch_bounds__(IPO_TB) void ipo_kernel(const float *__restrict__ x
         const float gk = ts * (-2.f * G00 * kk - G01 * r + G02 * i + G10 * r - 2.f * G11 * kk + G12 * j + G20 * i + G21 * j) + dts * kk;
         const float gs = (sc.p >= min_s && sc.p <= max_s) ? gsc : 0.f;   // clamp backward
         b1p *= 0.9; b2p *= 0.999;
-        const float step_size = (float)(0.1 / (1.0 - b1p));
-        const float bc2s = (float)sqrt(1.0 - b2p);
+        const int ta = it_begin + it;              // Adam's step count - 1
+        float step_size, bc2s;
+        if (ta < IPO_TABLE) { step_size = c_adam_step[ta]; bc2s = c_adam_bc2s[ta]; }
+        else { step_size = (float)(0.1 / (1.0 - b1p)); bc2s = (float)sqrt(1.0 - b2p); }
         qr.step(gr, step_size, bc2s);
         if (ax) qi.step(gi, step_size, bc2s);
         if (ay) qj.step(gj, step_size, bc2s);
         if (az) qk.step(gk, step_size, bc2s);
         sc.step(gs, step_size, bc2s);
     }
-    {
+    if (row_ok && jl == 0) {
         const float r = qr.p, i = qi.p, j = qj.p, kk = qk.p;
         const float ts = 2.0f / (r * r + i * i + j * j + kk * kk);
         float *Ro = Rout + (size_t)b * 9;
@@ -373,16 +488,39 @@ __global__ __launch_bounds__(IPO_TB) void ipo_kernel(const float *__restrict__ x
     }
 }
 
+// the Adam table of this device, once (a blocking copy: the only synchronising step of the first fit on a device)
+static hipError_t ensure_adam_table() {
+    static std::atomic<bool> done[MAX_DEVICES];
+    const int slot = device_slot();
+    if (slot >= 0 && done[slot].load(std::memory_order_acquire)) return hipSuccess;
+    static float h_step[IPO_TABLE], h_bc2s[IPO_TABLE];
+    static std::atomic<bool> host_ready{false};
+    if (!host_ready.load(std::memory_order_acquire)) {
+        double b1p = 1.0, b2p = 1.0;
+        for (int t = 0; t < IPO_TABLE; ++t) {
+            b1p *= 0.9; b2p *= 0.999;
+            h_step[t] = (float)(0.1 / (1.0 - b1p));
+            h_bc2s[t] = (float)sqrt(1.0 - b2p);
+        }
+        host_ready.store(true, std::memory_order_release);   // a racing thread writes the same values
+    }
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_adam_step), h_step, sizeof(h_step));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_adam_bc2s), h_bc2s, sizeof(h_bc2s));
+    if (e == hipSuccess && slot >= 0) done[slot].store(true, std::memory_order_release);
+    return e;
+}
+
 hipError_t launch_ipo_fit(const float *x0, const float *uv, const float *K, const int *h_keylist, int k,
                           int axes_mask, float ipo_T, float min_scale, float max_scale, int iters,
                           double normaliser, float *R, float *T, float *q, float *scale, float *state, int it_begin,
                           int B, int N, int J, long long row_offset, hipStream_t st) {
     if (k < 1 || k > IPO_KMAX) return hipErrorInvalidValue;
+    if (hipError_t e = ensure_adam_table(); e != hipSuccess) return e;
     double b1p0 = 1.0, b2p0 = 1.0;
     for (int i = 0; i < it_begin; ++i) { b1p0 *= 0.9; b2p0 *= 0.999; }   // the same running products the kernel forms
     IpoKeys keys{};
     for (int i = 0; i < k; ++i) keys.j[i] = h_keylist[i];
-    hipLaunchKernelGGL(ipo_kernel, dim3((B + IPO_TB - 1) / IPO_TB), dim3(IPO_TB), 0, st, x0, uv, K, keys, k,
+    hipLaunchKernelGGL(ipo_kernel, dim3((B + 1) / 2), dim3(64), 0, st, x0, uv, K, keys, k,
                        axes_mask, ipo_T, min_scale, max_scale, iters, (float)(1.0 / normaliser), R, T, q, scale, state,
                        it_begin, b1p0, b2p0, B, N, J, row_offset);
     return hipGetLastError();

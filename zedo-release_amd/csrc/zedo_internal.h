@@ -4,7 +4,43 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace zedo {
+
+// ---- per-device launch state ----------------------------------------------------------------------------------
+// The dense kernels ask for more dynamic LDS than the 64 KB default, which must be allowed once per kernel AND per
+// device; the CU count that drives the tile split is a property of the device too.  Both are cached per device index
+// below MAX_DEVICES; a device index beyond that is NOT aliased onto another device's slot: it pays the (cheap) query /
+// attribute call every launch.  The flags are idempotent (a race sets the attribute twice).
+constexpr int MAX_DEVICES = 16;
+inline int device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return (dev >= 0 && dev < MAX_DEVICES) ? dev : -1;
+}
+inline hipError_t allow_lds(const void *kern, size_t lds, std::atomic<bool> *done /* [MAX_DEVICES] */) {
+    const int slot = device_slot();
+    if (slot < 0 || !done[slot].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (slot >= 0) done[slot].store(true, std::memory_order_release);
+    }
+    return hipSuccess;
+}
+inline int num_cus() {
+    static std::atomic<int> n[MAX_DEVICES];
+    const int slot = device_slot();
+    int v = slot >= 0 ? n[slot].load(std::memory_order_relaxed) : 0;
+    if (!v) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        (void)hipGetDevice(&dev);
+        v = (hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+        if (slot >= 0) n[slot].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 
 constexpr int HID = 1024;    // hidden width of ScoreModelFC_Adv (reference run/opt_main.py:35)
 constexpr int EMB = 512;     // time-embedding width (run/opt_main.py:36)
@@ -19,6 +55,7 @@ enum Epilogue : int {
     EPI_SDE = 2,          // out = a*out + c*(acc + bias)                        (x' = a x + c eps)
     EPI_BIAS = 3,         // out = acc + bias
     EPI_BIAS_SILU = 4,    // out = SiLU(acc + bias)
+    EPI_PARTIAL = 5,      // out = acc of ONE K quarter, no bias (post_dense on small batches: see LayerArgs::scratch)
 };
 
 // One dense layer out[M][N] (+epilogue) = X[M][K] . W[N][K]^T ; all row-major fp32, K contiguous.
@@ -43,7 +80,14 @@ struct LayerArgs {
     float *rp_T;            // [rows][3], row 0 = first row of this launch
     int rp_solve, rp_B, rp_N;   // least-squares T?, valid rows of this launch, poses
     long long rp_row0;      // global row index of row 0 of this launch
+    // post_dense (N == XLD) sums its K = 1024 products as FOUR quarter chains q0..q3 (k in [256 q, 256 q + 256), each an fma
+    // chain from zero) combined as ((q0 + q1) + q2) + q3 - in every launch shape, so that results do not depend on it:
+    // large batches fold the quarters inside one tile, batches of up to POST_SPLIT_ROWS rows give every quarter its own
+    // workgroup (4x the workgroups on a launch that otherwise fills 1/9 of the chip with 512-MFMA dependent chains) and
+    // combine them in post_reduce_kernel.  scratch: [Mp/32][4][32][64] floats for the quarter sums (small batches only).
+    float *scratch;
 };
+constexpr int POST_SPLIT_ROWS = 2048;     // measured: 886 rows 22.7 -> 16.3 us per step, 4 096 rows equal, 6 400 rows 22.8 -> 25.7
 
 hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st);
 
@@ -132,6 +176,12 @@ hipError_t launch_reproj_prepare(const float *uv, const float *K, const float *c
                                  float *conf_clamped, hipStream_t st);
 hipError_t launch_reproj_grad(const float *x, const float *geom, float *T, int solve_T, float *g, int B, int N,
                               int J, long long row_offset, hipStream_t st);
+// the second half of post_dense on small batches: x' = a x + c (((q0 + q1) + q2) + q3 + bias) on the padded state (sde != 0)
+// or eps = ((q0 + q1) + q2) + q3 + bias -> eps_out [Bp][64] (sde == 0), then - geom != nullptr - the reprojection correction of
+// the next iteration on rows < B, exactly as the fused epilogue of the large-batch tile does it
+hipError_t launch_post_reduce(float *xpad, const float *partial, const float *bias, float sde_a, float sde_c, int sde,
+                              float *eps_out, const float *geom, float *T, int solve_T, int B, int Bp, int N, long long row0,
+                              hipStream_t st);
 hipError_t launch_reproj_step_padded(float *xpad, const float *geom, float *T, int solve_T, int B, int N,
                                      long long row0, hipStream_t st);
 hipError_t launch_posemb(const float *t, int S, int Sp, float label_scale, float *pe, hipStream_t st);

@@ -166,6 +166,11 @@ __device__ __forceinline__ void epilogue_values(const f32x16 &acc, const f32x4 (
         }
         return;
     }
+    if constexpr (EPI == EPI_PARTIAL) {        // one K quarter of post_dense, raw: bias and the update follow in post_reduce_kernel
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = acc[e];
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll

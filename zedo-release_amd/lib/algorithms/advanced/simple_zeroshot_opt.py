@@ -73,17 +73,20 @@ def invalidate_ray_cache():
     _geom_tls.entries = []
 
 
-def _rays(uv, Kc, cc):
-    """zedo_reproj_prepare for (key2d, K, conf), reused while the SAME tensor objects come back unmodified
-    (object identity + storage address + version counter + shape): the reference's loop hands gradient_field_gen
-    identical condition / K / conf tensors 1000 times per hypothesis (run/opt_main.py:203-206).  Up to _GEOM_SLOTS
-    triples per thread, least recently used out first; the cached tensors are held (so that ids stay unique) until
-    they are displaced or invalidate_ray_cache() is called.  conf is clamped in place on every build, as the reference
-    does on every call (:64-66; idempotent)."""
+def _rays(key2d, K, conf):
+    """zedo_reproj_prepare for the CALLER's (key2d, K, conf), reused while the SAME tensor objects come back unmodified
+    (object identity + storage address + version counter + shape + dtype of the tensors the caller passed - not of
+    converted copies, which would be new objects on every call and never hit): the reference's loop hands
+    gradient_field_gen identical condition / K / conf tensors 1000 times per hypothesis (run/opt_main.py:203-206).
+    Conversion to contiguous fp32, the build, the singular-system count (one small device allocation + a stream sync)
+    and the in-place clamp of conf (:64-66; idempotent, so skipping it on a hit changes nothing) happen on a miss only.
+    Up to _GEOM_SLOTS triples per thread, least recently used out first; the caller's tensors are held (so that ids
+    stay unique) until they are displaced or invalidate_ray_cache() is called."""
     import zedo_hip
 
     def fingerprint():
-        return tuple((id(a), a.data_ptr(), a._version, tuple(a.shape)) if a is not None else None for a in (uv, Kc, cc))
+        return tuple((id(a), a.data_ptr(), a._version, tuple(a.shape), a.dtype) if a is not None else None
+                     for a in (key2d, K, conf))
 
     entries = getattr(_geom_tls, "entries", None)
     if entries is None:
@@ -93,9 +96,16 @@ def _rays(uv, Kc, cc):
         if e[0] == key:
             entries.append(entries.pop(i))
             return e[2], e[3]
+    uv = key2d.float().contiguous()
+    Kc = K.float().contiguous()
+    cc = None
+    if conf is not None:
+        cc = conf if (conf.is_contiguous() and conf.dtype == torch.float32) else conf.float().contiguous()
     geom = zedo_hip.reproj_prepare(uv, Kc, cc, cc)
+    if cc is not None and cc is not conf:
+        conf.copy_(cc)                                       # the clamp is observable on the caller's tensor (:64-66)
     singular = zedo_hip.reproj_degenerate(geom)              # once per (key2d, K, conf): step-invariant
-    entries.append((fingerprint(), (uv, Kc, cc), geom, singular))      # fingerprint AFTER the in-place clamp of conf
+    entries.append((fingerprint(), (key2d, K, conf), geom, singular))      # fingerprint AFTER the in-place clamp of conf
     del entries[:-_GEOM_SLOTS]
     return geom, singular
 
@@ -110,18 +120,13 @@ def gradient_field_gen(key2d, key3d, K, noise_type=None, t=None, conf=None, retu
     import zedo_hip
     std = 0.0001
     B, J = key3d.shape[0], key3d.shape[1]
-    uv = key2d.float().contiguous()
     x = key3d.float().contiguous()
-    Kc = K.float().contiguous()
-    if conf is not None:
-        cc = conf if (conf.is_contiguous() and conf.dtype == torch.float32) else conf.float().contiguous()
-        geom, singular = _rays(uv, Kc, cc)
-        if cc is not conf:
-            conf.copy_(cc)
-    else:
-        geom, singular = _rays(uv, Kc, None)
+    geom, singular = _rays(key2d, K, conf)
     if t is None:
-        if singular:          # torch.inverse(AtA) of the reference raises on a singular system (:89-92)
+        # torch.inverse(AtA) of the reference raises on a singular system (:89-92).  Here "singular" is the exact test
+        # den == 0 of the closed form, i.e. ONLY a pose whose camera rays all coincide exactly raises; a nearly singular
+        # system returns a huge T, as torch.inverse does above its own pivot threshold
+        if singular:
             raise torch.linalg.LinAlgError(zedo_hip.SINGULAR_MSG.format(n=singular))
         T = torch.empty((B, 3), dtype=torch.float32, device=x.device)      # written by the kernel (solve_T)
         g = zedo_hip.reproj_grad(x, geom, T, True)

@@ -54,6 +54,7 @@ SIGNATURES = {
     "zedo_profile_start": (_i, [_i, _i]),
     "zedo_profile_stop": (_i, [_vp, _vp, _vp]),
     "zedo_profile_shader_ghz": (_d, []),
+    "zedo_profile_bracket_ms": (_d, []),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = library/header mismatch: fail loudly
@@ -342,13 +343,18 @@ def profile_start(sample_every=16, max_samples=8192):
 
 
 def profile_stop():
-    """-> {class: dict(total_ms, samples, launches, avg_ms)} for the sampled kernel launches."""
+    """-> {class: dict(total_ms, samples, launches, avg_ms, avg_ms_raw)} for the sampled kernel launches.  avg_ms is the
+    bracketed duration minus what an empty bracket measures on the same stream (zedo_profile_bracket_ms, also returned
+    under the key "bracket_ms" of the hidden_dense entry); avg_ms_raw is the bracketed duration itself."""
     n = len(PROF_CLASSES)
     tot = (ctypes.c_double * n)()
     cnt = (ctypes.c_longlong * n)()
     seen = (ctypes.c_longlong * n)()
     _check(_lib.zedo_profile_stop(ctypes.cast(tot, _vp), ctypes.cast(cnt, _vp), ctypes.cast(seen, _vp)))
+    br = float(_lib.zedo_profile_bracket_ms())
     out = {k: dict(total_ms=tot[i], samples=int(cnt[i]), launches=int(seen[i]),
-                   avg_ms=(tot[i] / cnt[i] if cnt[i] else None)) for i, k in enumerate(PROF_CLASSES)}
+                   avg_ms_raw=(tot[i] / cnt[i] if cnt[i] else None),
+                   avg_ms=(max(tot[i] / cnt[i] - br, 0.0) if cnt[i] else None)) for i, k in enumerate(PROF_CLASSES)}
     out["hidden_dense"]["shader_clock_ghz"] = float(_lib.zedo_profile_shader_ghz()) or None
+    out["hidden_dense"]["bracket_ms"] = br
     return out
