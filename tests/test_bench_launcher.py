@@ -129,3 +129,47 @@ def test_device_side_subsampling_of_row_shards(N, H, k):
             (tag, got), g2, off = subsample(("rows", rows[lo:lo + cnt]), gt, k, lo)
             assert tag == "rows" and np.array_equal(g2, ref_gt)
             assert torch.equal(got, ref_rows[off:off + got.shape[0]]), (lo, cnt, off)
+
+
+def test_valid_ind_mask_is_one_scatter_and_scales_to_the_full_test_set():
+    """eval_multi(valid_ind=...) (reference h36m.py:396-397): the mask over device rows is built from ONE flat index list
+    and ONE scatter (a Python statement per pose took minutes at configs[3]'s 567 040 poses).  Equal to
+    the per-pose loop on every shard of a small problem; half a million poses in well under ten seconds on a CPU."""
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "zedo-release_amd"))
+    from lib.dataset._eval import valid_rows_mask
+    rng = np.random.default_rng(3)
+    N, H = 23, 7
+    vi = [sorted(rng.choice(H + 2, size=rng.integers(0, H), replace=False).tolist()) for _ in range(N)]     # some indices >= H, some poses empty
+    ok = np.zeros((H, N), bool)
+    for n in range(N):
+        for h in vi[n]:
+            if 0 <= h < H:
+                ok[h, n] = True
+    flat = ok.reshape(-1)
+    for lo, cnt in ((0, H * N), (5, 40), (H * N - 9, 9), (17, 1)):
+        got = valid_rows_mask(vi, N, lo, cnt, torch.device("cpu")).numpy()
+        assert np.array_equal(got, flat[lo:lo + cnt]), (lo, cnt)
+    N, H = 567040, 50
+    vi = [(n % H, (n * 7) % H, (n * 13) % H) for n in range(N)]
+    t0 = time.time()
+    m = valid_rows_mask(vi, N, 0, H * N, torch.device("cpu"))
+    dt = time.time() - t0
+    assert int(m.sum()) == sum(len(set(v)) for v in vi) and m.shape == (H * N,)
+    assert bool(m[(0 % H) * N + 0]) and bool(m[((5 * 7) % H) * N + 5]) and dt < 10.0, dt
+
+
+def test_ulp_perturbation_and_tile_split_helpers():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "zedo-release_amd"))
+    import bench
+    from lib.dataset import synthetic as syn
+    uv = syn.make_poses(50, seed=1)["db_2d"][:, :, :2]
+    assert np.array_equal(syn.perturb_ulp(uv, 0), uv)
+    p1, p1b, p2 = syn.perturb_ulp(uv, 5), syn.perturb_ulp(uv, 5), syn.perturb_ulp(uv, 6)
+    assert np.array_equal(p1, p1b) and not np.array_equal(p1, p2) and p1.dtype == np.float32
+    steps = (p1.view(np.int32).astype(np.int64) - uv.view(np.int32).astype(np.int64))
+    assert set(np.unique(steps)) == {-1, 0, 1}                     # one unit in the last place at most (positive floats)
+    for rows in (1, 64, 886, 2048, 2049, 6350, 8192, 12700, 20000, 50750, 1 << 20):
+        sp = bench.f16x3_tile_split(rows)
+        assert sum(r for _, _, r in sp) == -(-rows // 64) * 64 and all(r % bm == 0 for bm, _, r in sp)

@@ -1,0 +1,210 @@
+"""Calibrated end-to-end parity at BASELINE configs[2] (-m gpu): the reference's and the kernels' own REPRODUCIBILITY.
+
+The IPO (500 Adam iterations, lr 0.1, L1 loss; reference run/opt_main.py:180-195) does not converge, its last iterate is
+chaotic, and the 1000-step loop of the random-init fixture weights does not contract it away: two fp32 implementations
+whose every single iteration agrees to 2.4e-7 (test_hip_parity.py) end poses apart and their dataset-mean MPJPE differs by
+tenths of a millimetre - as does the reference against ITSELF.  Round 3 let that through on a 3-standard-error clause;
+this file replaces it with measured null distributions:
+
+  * detections moved by -1 / 0 / +1 ulp (lib/dataset/synthetic.py::perturb_ulp) re-draw the chaos without changing the
+    algorithm.  (Thread count does NOT: the reference's IPO and loop are bit-identical on 1, 4 and 8 threads.)
+  * reference side, captured in the build container (tools/gen_golden.py): the IPO end state of 16 / 8 / 8 such members of the
+    three configs[2] draws as quantile functions (driver_pw3d_full*_ipoens.npz), and the FULL run (IPO + 1000 steps +
+    selection) of four members of draw A (driver_pw3d_full_env{1..4}.npz, 2.4 CPU-hours each);
+  * HIP side, here: M members through the fused pipeline (3 s each).
+
+Asserted: every reference run's dataset-mean MPJPE lies inside the central 95 % of the HIP ensemble; PA-MPJPE within
+0.05 mm outright; the means of the two ensembles within max(0.05 mm, what the two ensembles' own spread can resolve);
+the IPO end-state distributions (rotation angle, depth scale, end-state loss) quantile by quantile within 8 single-member
+standard deviations of the ensembles.  Numbers go to gpurun_out/parity_report.jsonl."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+HIP_SEED0 = 100            # reference members use perturbation streams 1, 2, ...; the HIP members 101, 102, ...
+T975 = {3: 3.182, 4: 2.776, 5: 2.571, 7: 2.365, 8: 2.306, 11: 2.201, 15: 2.131, 16: 2.120, 23: 2.069, 31: 2.040, 32: 2.037}
+
+
+def t975(dof):
+    return T975[max(k for k in T975 if k <= dof)] if dof >= 3 else 4.303
+
+
+def _report(rec):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_report.jsonl", "a") as f:
+        f.write(json.dumps(rec) + "\n")
+
+
+class Draw:
+    """One configs[2] capture: inputs regenerated from the fixture's seeds, checked against its hash."""
+
+    def __init__(self, name):
+        import hashlib
+        from lib.dataset import synthetic as syn
+        self.name = name
+        g = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.g = g
+        self.N, self.H, self.S = int(g["N"]), int(g["H"]), int(g["S"])
+        self.d = syn.make_poses(self.N, seed=int(g["seed_pose"]), conf_mode=str(g["conf_mode"]))
+        self.cl = syn.make_clusters(self.H, seed=int(g["seed_cl"]))
+        h = hashlib.sha256()
+        for a in (self.d["db_2d"], self.d["camera_param"], self.cl):
+            h.update(np.ascontiguousarray(a).tobytes())
+        assert h.hexdigest() == str(g["inputs_sha"]), "inputs differ from the captured run"
+        self.keylist = [int(k) for k in g["keylist"]]
+        self.ipo_T, self.minT = float(g["ipo_T"]), float(g["minT"])
+        self.gt = (self.d["db_3d"] - self.d["db_3d"][:, 0:1]).astype(np.float64)
+
+    def detections(self, seed):
+        from lib.dataset import synthetic as syn
+        db2 = self.d["db_2d"].copy()
+        db2[:, :, :2] = syn.perturb_ulp(db2[:, :, :2], seed)
+        return db2
+
+    def pipeline(self, W, seed):
+        from zedo_hip.pipeline import Pipeline, ZeDOConfig
+        cfg = ZeDOConfig(IPO_keylist=self.keylist, IPO_T=self.ipo_T, IPO_minScaleT=self.minT, OIL_iterations=self.S)
+        return Pipeline(W, cfg, "cuda").load(self.cl, self.detections(seed), self.d["camera_param"]), cfg
+
+    def ipo_summary(self, W, seed):
+        import zedo_hip
+        import _ipo_summary as ips
+        pipe, cfg = self.pipeline(W, seed)
+        R, T = zedo_hip.ipo_fit(pipe.x0, pipe.uv, pipe.K, cfg.IPO_keylist, cfg.RotAxes, cfg.IPO_T, cfg.IPO_minScaleT, cfg.IPO_maxScaleT,
+                                cfg.IPO_iterations, self.N * len(cfg.IPO_keylist) * 2, self.H * self.N)
+        cs = torch.stack([R[:, 0, 0], R[:, 1, 0]], -1).reshape(self.H, self.N, 2).cpu().numpy()
+        return ips.summary(cs, T.reshape(self.H, self.N, 3).cpu().numpy(), (self.cl - self.cl[:, 0:1])[:, None],
+                           self.detections(seed)[:, :, :2], self.d["camera_param"], cfg.IPO_keylist, cfg.IPO_T)
+
+    def end_to_end(self, W, seed):
+        import zedo_hip
+        pipe, _ = self.pipeline(W, seed)
+        x, _ = pipe.run()
+        gt = torch.as_tensor(self.gt, device="cuda")
+        _, b1, _ = zedo_hip.min_mpjpe(x, gt, self.N, procrustes=False)
+        _, b2, _ = zedo_hip.min_mpjpe(x, gt, self.N, procrustes=True)
+        return float(b1.mean().item()) * 1e3, float(b2.mean().item()) * 1e3            # mm
+
+
+@pytest.fixture(scope="module")
+def W(weights0, math_mode):
+    import zedo_hip
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return zedo_hip.Weights(weights0)
+
+
+DRAWS = ["driver_pw3d_full", "driver_pw3d_full_b", "driver_pw3d_full_c"]
+
+
+@pytest.mark.parametrize("name", DRAWS)
+def test_ipo_end_state_distribution_matches_the_references(W, math_mode, name):
+    """SURVEY 7 stage (B) "distributional checks at 500 (final L1 loss, scale histogram)", asserted (round 3 only logged the
+    comparison): 201-point quantile functions of the rotation angle about z, the depth scale T_z / T0_z and the end-state
+    reprojection loss over the 50 750 (hypothesis, pose) fits - ensemble mean of 12 HIP members against the ensemble mean of
+    the reference's members, tolerance per quantile = 8 x the pooled single-member standard deviation of the two ensembles
+    (floors 2e-4 rad / 1e-5 / 2e-4 px where a quantile does not move at all), i.e. TAKEN FROM THE ENSEMBLES.  Measured:
+    <= 4.8 (angle), 1.1 (scale), 6.0 (loss) such deviations; in absolute terms 6e-3 rad, 1.4e-3, 1.3e-2 px of 43."""
+    if math_mode != "f32":
+        pytest.skip("the IPO kernel does not depend on the arithmetic mode of the dense layers: covered by the f32 session")
+    dr = Draw(name)
+    ref = np.load(os.path.join(GOLDEN, name + "_ipoens.npz"))
+    assert str(ref["inputs_sha"]) == str(dr.g["inputs_sha"])
+    ms = [dr.ipo_summary(W, HIP_SEED0 + i) for i in range(1, 13)]
+    hip = {k: np.stack([np.asarray(m[k]) for m in ms]) for k in ms[0]}
+    rec = {"test": "ipo_end_state_distribution", "capture": name, "members_hip": len(ms), "members_ref": int(ref["q_loss"].shape[0])}
+    sl = slice(2, -2)          # the outermost 1 % on either side are single extreme rows
+    for k, floor, abs_tol in (("q_angle", 2e-4, 1.2e-2), ("q_scale", 1e-5, 3e-3), ("q_loss", 2e-4, 3e-2)):
+        a, b = ref[k], hip[k]
+        d = np.abs(a.mean(0) - b.mean(0))[sl]
+        sd = np.maximum(np.sqrt((a.var(0, ddof=1) + b.var(0, ddof=1)) / 2)[sl], floor)
+        rec[k] = dict(max_abs_diff=float(d.max()), max_in_member_sd=float((d / sd).max()), median_in_member_sd=float(np.median(d / sd)))
+        assert (d <= 8.0 * sd).all(), (k, rec[k])
+        assert d.max() <= abs_tol, (k, rec[k])
+    dm = float(ref["mean_loss"].mean() - hip["mean_loss"].mean())
+    rec["mean_loss_px"] = dict(ref=float(ref["mean_loss"].mean()), hip=float(hip["mean_loss"].mean()), diff=dm,
+                               member_sd_ref=float(ref["mean_loss"].std(ddof=1)), member_sd_hip=float(hip["mean_loss"].std(ddof=1)))
+    _report(rec)
+    assert abs(dm) <= 3e-3, rec["mean_loss_px"]                  # of ~43 px: 7e-5 relative (measured <= 1.2e-3)
+
+
+def _members(name, math_mode):
+    if math_mode != "f32":
+        return 8                # the split-fp16 mode shares the IPO kernel bit for bit; a short ensemble shows its loop agrees
+    return 32 if name == "driver_pw3d_full" else 12
+
+
+_ENSEMBLES = {}
+
+
+@pytest.mark.parametrize("name", DRAWS)
+def test_reference_runs_lie_inside_the_hip_ensemble(W, math_mode, name):
+    """The north-star number at configs[2] with a calibrated yardstick.  HIP ensemble: M ulp-perturbed members of the capture
+    through the fused pipeline (IPO + 1000 steps + selection).  Reference: the captured run and - draw A - four more
+    ulp-perturbed members of the REFERENCE's own run (2.4 CPU-hours each: its fp32 reproducibility envelope).
+      (a) every reference run's dataset-mean MPJPE inside the central 95 % of the HIP ensemble (t prediction interval);
+      (b) PA-MPJPE: every reference run within 0.05 mm of the HIP ensemble mean - the bar, outright;
+      (c) MPJPE: HIP ensemble mean within max(0.05 mm, E) of the reference mean, E = what the two ensembles can resolve:
+          t(0.975) x pooled member sd x sqrt(1/M + 1/K) - with the member sd of the REFERENCE where it has members."""
+    dr = Draw(name)
+    M = _members(name, math_mode)
+    e = np.array([dr.end_to_end(W, HIP_SEED0 + i) for i in range(1, M + 1)])
+    _ENSEMBLES[(name, math_mode)] = e
+    refs = [(float(dr.g["mpjpe"]) * 1e3, float(dr.g["pa_mpjpe"]) * 1e3)]
+    k = 1
+    while os.path.exists(os.path.join(GOLDEN, f"{name}_env{k}.npz")):
+        z = np.load(os.path.join(GOLDEN, f"{name}_env{k}.npz"))
+        assert int(z["perturb"]) == k
+        refs.append((float(z["mpjpe"]) * 1e3, float(z["pa_mpjpe"]) * 1e3))
+        k += 1
+    refs = np.array(refs)
+    m1, s1 = e[:, 0].mean(), e[:, 0].std(ddof=1)
+    half = t975(M - 1) * s1 * np.sqrt(1 + 1 / M)
+    K = len(refs)
+    s_ref = refs[:, 0].std(ddof=1) if K >= 3 else None
+    sp = np.sqrt(((M - 1) * s1 ** 2 + (K - 1) * s_ref ** 2) / (M + K - 2)) if s_ref is not None else s1
+    E = t975(M + K - 2) * sp * np.sqrt(1 / M + 1 / K)
+    rec = {"test": "end_to_end_ensemble", "capture": name, "math": math_mode, "members_hip": M, "reference_runs": K,
+           "mpjpe_mm": dict(hip_mean=float(m1), hip_member_sd=float(s1), hip_min=float(e[:, 0].min()), hip_max=float(e[:, 0].max()),
+                            central95_half_width=float(half), reference=[float(v) for v in refs[:, 0]],
+                            reference_member_sd=(float(s_ref) if s_ref is not None else None),
+                            reference_max_pairwise=float(refs[:, 0].max() - refs[:, 0].min()),
+                            mean_diff=float(m1 - refs[:, 0].mean()), resolvable=float(E)),
+           "pa_mpjpe_mm": dict(hip_mean=float(e[:, 1].mean()), hip_member_sd=float(e[:, 1].std(ddof=1)), reference=[float(v) for v in refs[:, 1]],
+                               max_diff=float(np.abs(refs[:, 1] - e[:, 1].mean()).max()))}
+    _report(rec)
+    print(json.dumps(rec))
+    assert (np.abs(refs[:, 0] - m1) <= half).all(), rec["mpjpe_mm"]                       # (a)
+    assert rec["pa_mpjpe_mm"]["max_diff"] <= 0.05, rec["pa_mpjpe_mm"]                     # (b)
+    assert abs(m1 - refs[:, 0].mean()) <= max(0.05, E), rec["mpjpe_mm"]                   # (c)
+
+
+def test_pooled_over_the_three_draws(math_mode):
+    """The three draws together: mean over draws of (HIP ensemble mean - reference mean), against what three such
+    differences can resolve.  A bare 0.05 mm here would need >= 60 reference runs per draw (member sd 0.2 mm): the number is
+    reported, the assertion is max(0.05 mm, 2 standard errors from the measured member spreads)."""
+    if any((n, math_mode) not in _ENSEMBLES for n in DRAWS):
+        pytest.skip("needs the ensembles of test_reference_runs_lie_inside_the_hip_ensemble from this session")
+    diffs, var = [], 0.0
+    for n in DRAWS:
+        e = _ENSEMBLES[(n, math_mode)][:, 0]
+        g = np.load(os.path.join(GOLDEN, n + ".npz"))
+        refs = [float(g["mpjpe"]) * 1e3]
+        k = 1
+        while os.path.exists(os.path.join(GOLDEN, f"{n}_env{k}.npz")):
+            refs.append(float(np.load(os.path.join(GOLDEN, f"{n}_env{k}.npz"))["mpjpe"]) * 1e3)
+            k += 1
+        diffs.append(e.mean() - np.mean(refs))
+        s = e.std(ddof=1)
+        var += s ** 2 / len(e) + s ** 2 / len(refs)          # the reference's member spread taken equal to the kernels' (measured: it is)
+    pooled, se = float(np.mean(diffs)), float(np.sqrt(var) / len(DRAWS))
+    _report({"test": "end_to_end_ensemble_pooled", "math": math_mode, "per_draw_mean_diff_mm": [float(d) for d in diffs], "pooled_mm": pooled,
+             "standard_error_mm": se})
+    assert abs(pooled) <= max(0.05, 2.0 * se), (pooled, se, diffs)

@@ -154,6 +154,52 @@ def test_oil_loop_golden_snapshots(zh, W, golden, S):
     assert rows[0]["hip_vs_ref32"] <= 2e-6          # one step: round-off
 
 
+ALT_WEIGHTS = {"w1": dict(seed=1), "tied": dict(seed=0, prior="tied")}
+
+
+@pytest.mark.parametrize("tag", sorted(ALT_WEIGHTS))
+def test_single_call_goldens_on_other_weights(zh, golden, math_mode, tag):
+    """every parity number was on ONE synthetic weight set.  The single-call goldens again on a second
+    random draw (seed 1) and on the contractive "tied" prior (lib/dataset/synthetic.py::make_weights), captured from the
+    reference by tools/gen_golden.py::gen_weights_alt - the same tolerances as the seed-0 tests above: time-bias rows
+    5e-6, network output 2e-6, pc_sampler's x_mean 5e-7, the 100-step loop by the fp64-arbiter criterion."""
+    import zedo_oracle as O
+    from lib.dataset import synthetic as syn
+    g = golden("weights_alt")
+    w = syn.make_weights(**ALT_WEIGHTS[tag])
+    assert syn.weights_checksum(w) == str(g[f"sha_{tag}"])
+    Wt = zh.Weights(w)
+    s = zh.Schedule(Wt, g["ts"])
+    np.testing.assert_allclose(s.read()[0], g[f"tbias_{tag}"], atol=5e-6, rtol=0)
+    for i in range(len(g["ts"])):
+        eps = zh.score_eps(Wt, s, i, dev(g["x"])).cpu().numpy()
+        # per unit of output: the tied prior's eps is 60x larger than the random draws' (max |eps| 13.7)
+        np.testing.assert_allclose(eps, g[f"eps_{tag}"][i], atol=2e-6 * max(1.0, float(np.abs(g[f"eps_{tag}"][i]).max())), rtol=0)
+    s1000 = zh.Schedule(Wt, O.oil_timestamps(1000))
+    for k, i in enumerate(g["idx_1000"]):
+        x = dev(g["x"])
+        zh.sde_step(Wt, s1000, int(i), x)
+        np.testing.assert_allclose(x.cpu().numpy(), g[f"xmean_{tag}"][k], atol=5e-7, rtol=0)
+    S, steps = 100, [int(v) for v in g["snap_steps"]]
+    sched = zh.Schedule(Wt, O.oil_timestamps(S))
+    N = g["x_init"].shape[0]
+    geom = zh.reproj_prepare(dev(g["db2d"][:, :, :2]), dev(g["K"]), dev(g["db2d"][:, :, 2]))
+    x, T = dev(g["x_init"]), dev(g["T_init"].reshape(N, 3))
+    gap = np.abs(g[f"snaps_{tag}_f32"] - g[f"snaps_{tag}_f64"]).reshape(len(steps), -1).max(1)
+    prev, rows = 0, []
+    for i, st in enumerate(steps):
+        zh.oil_run(Wt, sched, x, geom, T, prev, st, S // 5)
+        prev = st
+        xn = x.cpu().numpy()
+        rows.append(dict(step=st, hip_vs_ref64=float(np.abs(xn - g[f"snaps_{tag}_f64"][i]).max()),
+                         hip_vs_ref32=float(np.abs(xn - g[f"snaps_{tag}_f32"][i]).max()), ref32_vs_ref64=float(gap[i])))
+    _report(f"oil_alt_weights_{tag}", rows)
+    for r in rows:
+        assert r["hip_vs_ref64"] <= 1.5 * r["ref32_vs_ref64"] + 2e-6, r
+        assert r["hip_vs_ref32"] <= 2.5 * r["ref32_vs_ref64"] + 2e-6, r
+    np.testing.assert_allclose(T.cpu().numpy(), g[f"T_final_{tag}_f64"].reshape(N, 3), atol=1.5 * float(np.abs(g[f"T_final_{tag}_f32"] - g[f"T_final_{tag}_f64"]).max()) + 2e-5, rtol=0)
+
+
 def test_oil_loop_vs_oracle_ragged(zh, W, weights0):
     """B = H*N rows with H=3, N=37 (B not a multiple of any tile), 30 steps, switch at 6; same criterion
     with the oracle run in fp64 as arbiter and in fp32 as the reference-precision run."""

@@ -34,6 +34,33 @@ def test_score_network_forward(golden, weights0):
     np.testing.assert_allclose(pe, g["pe"], atol=5e-5, rtol=0)
 
 
+@pytest.mark.parametrize("tag,kw", [("w1", dict(seed=1)), ("tied", dict(seed=0, prior="tied"))])
+def test_oracle_on_other_weights(golden, tag, kw):
+    """The oracle against the reference on a second weight draw and on the contractive "tied" prior
+    (tools/gen_golden.py::gen_weights_alt): network output, time-bias rows, pc step, and the 100-step loop."""
+    g = golden("weights_alt")
+    w = syn.make_weights(**kw)
+    assert syn.weights_checksum(w) == str(g[f"sha_{tag}"])
+    for i, t in enumerate(g["ts"]):
+        eps = O.score_model_forward(w, g["x"], np.float32(t) * np.float32(999))
+        # the tied prior's output is 60x larger (max |eps| 13.7: post_dense = pre_dense^T, no 0.1 gain): tolerance per unit of output
+        np.testing.assert_allclose(eps, g[f"eps_{tag}"][i], atol=1e-6 * max(1.0, float(np.abs(g[f"eps_{tag}"][i]).max())), rtol=0)
+    np.testing.assert_allclose(O.time_bias_table(w, g["ts"] * np.float32(999)), g[f"tbias_{tag}"], atol=3e-6, rtol=0)
+    ts = O.oil_timestamps(1000)
+    for k, i in enumerate(g["idx_1000"]):
+        np.testing.assert_allclose(O.pc_step(w, g["x"], ts[i]), g[f"xmean_{tag}"][k], atol=2e-7, rtol=0)
+    N = g["x_init"].shape[0]
+    snaps = {int(s_): None for s_ in g["snap_steps"]}
+    x, T = O.oil_loop(w, g["x_init"], g["db2d"][:, :, :2], g["K"], g["db2d"][:, :, 2].copy(), g["T_init"], 100, snapshots=snaps)
+    gap = np.abs(g[f"snaps_{tag}_f32"] - g[f"snaps_{tag}_f64"]).reshape(3, -1).max(1)
+    for i, s_ in enumerate(g["snap_steps"]):
+        assert np.abs(snaps[int(s_)] - g[f"snaps_{tag}_f64"][i]).max() <= 1.5 * gap[i] + 2e-6
+    # the tied prior contracts: the reference's own fp32 and fp64 runs end closer together than on a random draw
+    if tag == "tied":
+        gap_w1 = np.abs(g["snaps_w1_f32"] - g["snaps_w1_f64"]).reshape(3, -1).max(1)
+        assert gap[-1] < gap_w1[-1]
+
+
 @pytest.mark.parametrize("S", [1000, 100])
 def test_pc_step_and_schedule(golden, weights0, S):
     p = golden("pc_step")

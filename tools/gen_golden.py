@@ -117,6 +117,53 @@ def gen_model():
          pe_labels=lab.numpy(), pe=pe[::37])
 
 
+ALT_WEIGHTS = {"w1": dict(seed=1), "tied": dict(seed=0, prior="tied")}
+
+
+def gen_weights_alt():
+    """The single-call goldens again on OTHER weights (every capture used make_weights(seed=0)):
+    a second random draw (seed 1) and the contractive "tied" prior - network output at three noise levels, the time-bias
+    rows, pc_sampler's x_mean at four steps of the 1000-step schedule, and the 100-step loop from a pinned (R, T) on 12
+    poses in fp32 and fp64 (snapshots 20 / 21 / 100: across the switch to the least-squares T)."""
+    g = np.random.Generator(np.random.Philox(key=[7, 11]))
+    x = (0.3 * g.standard_normal((8, 17, 3))).astype(np.float32)
+    ts3 = np.array([0.1, 0.0555, 0.01], dtype=np.float32)
+    N = 12
+    d = syn.make_poses(N, seed=23, conf_mode="uniform")
+    cl = syn.make_clusters(1, seed=8)
+    x0 = np.broadcast_to((cl - cl[:, 0:1])[0][None], (N, 17, 3)).astype(np.float32).copy()
+    ang = g.uniform(-np.pi, np.pi, N)
+    R = np.zeros((N, 3, 3), np.float32)
+    R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1], R[:, 2, 2] = np.cos(ang), -np.sin(ang), np.sin(ang), np.cos(ang), 1
+    T = (d["db_3d"][:, 0:1, :] * (1 + 0.05 * g.standard_normal((N, 1, 1)))).astype(np.float32)
+    xi = np.einsum("bij,bkj->bki", R, x0).astype(np.float32)
+    out = dict(x=x, ts=ts3, db2d=d["db_2d"], K=d["camera_param"], x_init=xi, T_init=T, snap_steps=np.array([20, 21, 100]))
+    fn = ref_sampling_fn(8)
+    for tag, kw in ALT_WEIGHTS.items():
+        w = syn.make_weights(**kw)
+        m = ref_model(w)
+        out[f"sha_{tag}"] = np.array(syn.weights_checksum(w))
+        eps, tbias = [], []
+        with torch.no_grad():
+            for t in ts3:
+                labels = torch.ones(8) * torch.tensor(t) * 999
+                eps.append(m(torch.tensor(x), labels, None, None).numpy())
+                temb = m.shared_time_embed(get_timestep_embedding(labels[:1], 512))
+                tbias.append(np.stack([(getattr(m, n + "_t")(temb) + getattr(m, n).bias).numpy()[0]
+                                       for n in ["pre_dense", "b1_dense1", "b1_dense2", "b2_dense1", "b2_dense2"]]))
+        out[f"eps_{tag}"], out[f"tbias_{tag}"] = np.stack(eps), np.stack(tbias)
+        tl = torch.linspace(0.1, 0.01, 1000)
+        idx = [0, 199, 200, 999]
+        out["idx_1000"] = np.array(idx)
+        out[f"xmean_{tag}"] = np.stack([fn(m, condition=torch.zeros(8, 17, 2), denoise_x=torch.tensor(x), t=tl[i], t_step=i)[1] for i in idx])
+        for dt_tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            mm = m if dt == torch.float32 else ref_model(w, torch.float64)
+            res, Tf, got = run_ref_oil(mm, xi, d["db_2d"][:, :, :2], d["db_2d"][:, :, 2].copy(), d["camera_param"], T, 100, [20, 21, 100], dt)
+            out[f"snaps_{tag}_{dt_tag}"] = np.stack([got[k] for k in (20, 21, 100)])
+            out[f"T_final_{tag}_{dt_tag}"] = Tf
+    save("weights_alt", **out)
+
+
 def gen_pc_step():
     w = syn.make_weights(seed=0)
     m = ref_model(w)
@@ -721,6 +768,34 @@ def gen_driver_full():
          batch_results=batch_results.astype(np.float32))
 
 
+def gen_driver_full_env():
+    """The reference's own fp32 reproducibility on the gen_driver_full problem (N = 160, H = 3, S = 1000, 3DPW settings): the
+    same run on detections moved by -1/0/+1 ulp (syn.perturb_ulp streams 1..6) - dataset means only."""
+    w = syn.make_weights(seed=0)
+    m = ref_model(w)
+    N, H, S = 160, 3, 1000
+    d = syn.make_poses(N, seed=57, conf_mode="uniform")
+    cl = syn.make_clusters(H, seed=13)
+    K = d["camera_param"]
+    pw = _pw3d_obj(d["db_3d"])
+    p1s, p2s = [], []
+    for run in range(1, 7):
+        gt_2d = d["db_2d"].copy()
+        gt_2d[:, :, :2] = syn.perturb_ulp(gt_2d[:, :, :2], run)
+        batch_results = []
+        for sid in range(H):
+            noisy = torch.ones_like(torch.tensor(d["db_3d"])) * torch.tensor(cl - cl[:, 0:1, :])[sid:sid + 1]
+            r = run_ref_ipo(noisy.numpy(), gt_2d[:, :, :2], K, "z", list(range(17)), 8.0, 0.2, 2.0, 500, trace_upto=1)
+            x = torch.tensor(r["R"]).bmm(noisy.permute(0, 2, 1)).permute(0, 2, 1).contiguous().numpy()
+            res, _, _ = run_ref_oil(m, x, gt_2d[:, :, :2], gt_2d[:, :, 2].copy(), K, r["T"], S, [])
+            batch_results.append(res)
+        br = np.swapaxes(np.array(batch_results), 0, 1)
+        p1s.append(pw.eval_multi(br, protocol2=False))
+        p2s.append(pw.eval_multi(br, protocol2=True))
+        print(f"  driver_full env member {run}: {p1s[-1]:.6f} {p2s[-1]:.6f}", flush=True)
+    save("driver_full_env", members=np.arange(1, 7), mpjpe=np.array(p1s, np.float64), pa_mpjpe=np.array(p2s, np.float64))
+
+
 def _driver_full_size(tag, N, H, S, seed_pose, seed_cl, keylist, ipo_T, minT, conf_mode, dataset, cache_dir,
                       dtype=torch.float32, perturb=0, weights=None):
     """opt_main.py:166-228 at a BASELINE configuration's stated size.  One hypothesis at a time like the reference;
@@ -1002,7 +1077,7 @@ def gen_driver_pw3d_full_c_oil64():
 
 
 
-GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo, oil=gen_oil,
+GENS = dict(model=gen_model, weights_alt=gen_weights_alt, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo, oil=gen_oil,
             eval=gen_eval, driver=gen_driver, datasets=gen_datasets,
             driver_files=gen_driver_files, samplers=gen_samplers, pc_generic=gen_pc_generic, hp3d_ski=gen_3dhp_ski, driver_full=gen_driver_full,
             driver_h36m_full=gen_driver_h36m_full, driver_pw3d_full=gen_driver_pw3d_full,
@@ -1010,9 +1085,9 @@ GENS = dict(model=gen_model, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo
             driver_pw3d_full_b=gen_driver_pw3d_full_b, driver_pw3d_full_c=gen_driver_pw3d_full_c,
             driver_ipo_pins=gen_driver_ipo_pins, driver_pw3d_full_oil64=gen_driver_pw3d_full_oil64, driver_pw3d_full_b_oil64=gen_driver_pw3d_full_b_oil64,
             driver_pw3d_full_c_oil64=gen_driver_pw3d_full_c_oil64, driver_pw3d_full_env=gen_driver_pw3d_full_env,
-            driver_pw3d_ipoens=gen_driver_pw3d_ipoens, driver_pw3d_full_tied=gen_driver_pw3d_full_tied)
+            driver_pw3d_ipoens=gen_driver_pw3d_ipoens, driver_pw3d_full_tied=gen_driver_pw3d_full_tied, driver_full_env=gen_driver_full_env)
 SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64", "driver_pw3d_full_b", "driver_pw3d_full_c", "driver_ipo_pins", "driver_pw3d_full_oil64", "driver_pw3d_full_b_oil64",
-        "driver_pw3d_full_c_oil64", "driver_pw3d_full_env", "driver_pw3d_ipoens", "driver_pw3d_full_tied"}     # only with --only
+        "driver_pw3d_full_c_oil64", "driver_pw3d_full_env", "driver_pw3d_ipoens", "driver_pw3d_full_tied", "driver_full_env"}     # only with --only
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
