@@ -674,18 +674,20 @@ def write_3dhp_asset(N=45, seed=91):
 def write_ski_asset(N=24, seed=93):
     """ski_test.h5 with the dataset keys the reader parses (skiPose.py:119-157): per frame 3D [51] (metres,
     camera frame), 2D [34] in 0..1 of the 256-pixel crop, cam_intrinsic [3,3] in crop units, seq / cam / frame.
-    Stored as an .npz archive under the .h5 name and served through tools/ref_stubs/h5py.py."""
+    A genuine HDF5 file, written through libhdf5 (tools/ref_stubs/h5py.py binds the C library; h5py is not installed)."""
+    import h5py
     d = syn.make_poses(N, seed=seed, dtype3d=np.float64)
     K = d["camera_param"].astype(np.float64)
     g = np.random.Generator(np.random.Philox(key=[seed, 7]))
     cam = K / 256.0
     cam[:, 2, 2] = 1.0 / 256.0 + 0.001 * g.standard_normal(N)       # the reader overwrites [2,2] with 1
     os.makedirs(os.path.join(ASSETS, "ski"), exist_ok=True)
-    with open(os.path.join(ASSETS, "ski", "ski_test.h5"), "wb") as f:
-        np.savez_compressed(f, **{"3D": d["db_3d"].reshape(N, 51).astype(np.float32),
-                                  "2D": (d["db_2d"][:, :, :2].astype(np.float64) / 256.0).reshape(N, 34),
-                                  "cam_intrinsic": cam, "seq": (np.arange(N) % 3).astype(np.float64),
-                                  "cam": (np.arange(N) % 6).astype(np.int64), "frame": (7 * np.arange(N)).astype(np.int64)})
+    with h5py.File(os.path.join(ASSETS, "ski", "ski_test.h5"), "w") as f:
+        for name, arr in (("3D", d["db_3d"].reshape(N, 51).astype(np.float32)),
+                          ("2D", (d["db_2d"][:, :, :2].astype(np.float64) / 256.0).reshape(N, 34)),
+                          ("cam_intrinsic", cam), ("seq", (np.arange(N) % 3).astype(np.float64)),
+                          ("cam", (np.arange(N) % 6).astype(np.int64)), ("frame", (7 * np.arange(N)).astype(np.int64))):
+            f.create_dataset(name, data=arr)
 
 
 def gen_3dhp_ski():

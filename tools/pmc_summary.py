@@ -31,7 +31,8 @@ def per_kernel(path):
 
 
 def short(name):
-    m = re.search(r"(layer_pair_kernel|layer_kernel|reproj_step_kernel|ipo_kernel)(<[^>]*>)?", name)
+    m = re.search(r"(layer16_pair_kernel|layer16_small_kernel|layer16_pre_kernel|layer16_post_kernel|layer_pair_kernel|layer_kernel|"
+                  r"post_reduce_kernel|reproj_step_kernel|ipo_kernel)(<[^>]*>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
 
@@ -50,9 +51,12 @@ def main():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("GRBM_GUI_ACTIVE"):
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs on the chip
             e["mfma_util"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] / 8 * 1024)
-    hidden = [e for k, e in merged.items() if k.startswith("layer_pair_kernel") and "hbm_bytes_per_launch" in e]
+    # ZEDO_PMC_HIDDEN: name prefix of the hidden-layer kernel of the profiled arithmetic mode (f16x3: layer16_pair_kernel)
     import os
+    hid = os.environ.get("ZEDO_PMC_HIDDEN", "layer_pair_kernel")
+    hidden = [e for k, e in merged.items() if k.startswith(hid) and "hbm_bytes_per_launch" in e]
     doc = {"note": __doc__.split("usage:")[1].split("\n", 2)[2].strip(), "rows": rows,
+           "rows_launch": rows, "hidden_kernel": hid,
            "collected": os.environ.get("ZEDO_PMC_TAG", "unlabelled counter pass"), "kernels": merged}
     if hidden:
         alg = rows * 1024 * 4 * 2.5 + 1024 * 1024 * 4      # read X, write Y, residual on every other layer, + W
