@@ -184,17 +184,20 @@ def test_fused_driver_full_length_matches_reference(weights0, golden):
                             "joint_dist_p99": float(np.percentile(dj, 99))}) + "\n")
     print(f"driver_full: MPJPE {p1:.6f} vs {float(d['mpjpe']):.6f}, PA {p2:.6f} vs {float(d['pa_mpjpe']):.6f}, "
           f"joint distance median {np.median(dj):.2e} p99 {np.percentile(dj, 99):.2e}")
-    # PA-MPJPE: the 0.05 mm bar.  Unaligned MPJPE of 160 best-of-3 values on this chaotic loop (final joints of two
-    # fp32 runs a median 2.4 mm apart): any one-ulp change of the arithmetic moves the mean by its sampling error
-    # std(per-pose delta)/sqrt(N) ~ 0.6 mm (round 1's 0.020 mm was a draw, -ffp-contract=off gave 0.81), so the bar
-    # is applied where it means something and the mean is otherwise held to 3 standard errors (no bias).
+    # PA-MPJPE: the 0.05 mm bar, outright.  Unaligned MPJPE: the bar, or the REFERENCE'S OWN fp32 reproducibility on this
+    # problem where that is wider - tests/golden/driver_full_env.npz holds the reference's run on six copies of the detections
+    # moved by -1/0/+1 ulp (tools/gen_golden.py::gen_driver_full_env): its dataset mean scatters by 0.28 mm (sd), 0.76 mm
+    # between the extremes of its seven runs (the IPO's chaotic last iterate through an expansive loop).  No standard-error
+    # clause: one number from fixtures.
     assert abs(p2 - float(d["pa_mpjpe"])) < 5e-5, (p2, float(d["pa_mpjpe"]))
-    gtc = (d["db_3d"] - d["db_3d"][:, 0:1]).astype(np.float64)
-    e_hip = np.linalg.norm(mine - gtc[:, None], axis=-1).mean(-1).min(1)
-    e_ref = np.linalg.norm(ref.astype(np.float64) - gtc[:, None], axis=-1).mean(-1).min(1)
-    assert abs(e_ref.mean() - float(d["mpjpe"])) < 1e-6
-    se = (e_hip - e_ref).std() / np.sqrt(len(e_ref))
-    assert abs(p1 - float(d["mpjpe"])) < max(5e-5, 3.0 * se), (p1, float(d["mpjpe"]), se)
+    env = golden("driver_full_env")
+    ref_runs = np.concatenate([[float(d["mpjpe"])], env["mpjpe"]])
+    envelope = float(ref_runs.max() - ref_runs.min())
+    with open("gpurun_out/parity_report.jsonl", "a") as f:
+        f.write(json.dumps({"test": "driver_full_envelope", "d_mpjpe_mm": (p1 - float(d["mpjpe"])) * 1e3, "reference_self_envelope_mm": envelope * 1e3,
+                            "reference_runs_mm": [float(v) * 1e3 for v in ref_runs]}) + "\n")
+    assert abs(p1 - float(d["mpjpe"])) <= max(5e-5, envelope), (p1, float(d["mpjpe"]), envelope)
+    assert np.abs(env["pa_mpjpe"] - float(d["pa_mpjpe"])).max() < 5e-5          # the reference against itself meets the bar in PA-MPJPE
 
 
 def test_reference_loop_through_the_per_step_surface(model, weights0):
@@ -343,24 +346,27 @@ def test_fused_driver_at_baseline_size_matches_reference(weights0, golden, name)
     with open("gpurun_out/parity_report.jsonl", "a") as f:
         f.write(json.dumps(rep) + "\n")
     print(json.dumps(rep))
-    # Bar of BASELINE.json: both dataset means within 0.05 mm of the reference.  The loop is chaotic with the
-    # random-init fixture weights (per-pose final errors of two fp32 runs differ by a median 0.1-0.3 mm and by
-    # centimetres in the tail, see the report), so a mean over N poses of a best-of-H carries a sampling error of
-    # std(per-pose delta)/sqrt(N); where that alone exceeds the bar (configs[2], MPJPE without alignment: depth along
-    # the ray is weakly constrained) a difference of dataset means says nothing, and the criterion becomes:
-    #   (i)  no significant bias: |mean per-pose delta| <= 3 standard errors;
-    #   (ii) the per-pose deviations from the fp64 arbiter are no larger than the reference's own fp32 run's
-    #        (median and 90th percentile within x1.5 + 0.02 mm) - the criterion of the loop tests, per pose.
-    for key, dm in (("p1", rep["d_mpjpe_mm"]), ("p2", rep["d_pa_mpjpe_mm"])):
-        if dm <= 0.05:
-            continue
-        se = rep[key]["standard_error_of_mean_delta_mm"]
-        assert abs(rep[key]["best_delta_mm"]["mean"]) <= 3.0 * se, (key, dm, se)
-        if arb is None:          # second draw (no float64 run of it): the bias test is what it is there for
-            assert name[-2:] in ("_b", "_c"), f"{key}: {dm:.3f} mm from the reference and no fp64 arbiter fixture to judge it by"
-            continue
-        h, r = arb[key]["hip_vs_ref64_mm"], arb[key]["ref32_vs_ref64_mm"]
-        assert h["median"] <= 1.5 * r["median"] + 0.02 and h["p90"] <= 1.5 * r["p90"] + 0.02, (key, h, r)
+    # Bar of BASELINE.json: both dataset means within 0.05 mm of the reference - or, where the REFERENCE's own fp32 run does
+    # not reproduce itself that closely, within its self-envelope: tests/golden/driver_pw3d_full_env{1..4}.npz are the
+    # reference's full run (IPO + 1000 steps + selection, 2.4 CPU-hours each) on four copies of draw A's detections moved by
+    # -1/0/+1 ulp; envelope = the largest difference between two of its five runs (all three configs[2] draws have the
+    # same shape and settings).  configs[1] (H36M settings, one hypothesis) meets 0.05 mm outright and has no envelope.
+    # The round-3 clause "|mean delta| <= 3 standard errors" is gone; the distributional side is tests/test_ensemble_gpu.py.
+    envelope = {"p1": 0.0, "p2": 0.0}
+    if not h36m:
+        runs = [golden("driver_pw3d_full")] + [golden(f"driver_pw3d_full_env{k}") for k in range(1, 5)]
+        envelope = {"p1": (max(float(r["mpjpe"]) for r in runs) - min(float(r["mpjpe"]) for r in runs)) * 1e3,
+                    "p2": (max(float(r["pa_mpjpe"]) for r in runs) - min(float(r["pa_mpjpe"]) for r in runs)) * 1e3}
+    with open("gpurun_out/parity_report.jsonl", "a") as f:
+        f.write(json.dumps({"test": name + "_envelope", "d_mpjpe_mm": rep["d_mpjpe_mm"], "d_pa_mpjpe_mm": rep["d_pa_mpjpe_mm"],
+                            "reference_self_envelope_mm": envelope}) + "\n")
+    assert rep["d_pa_mpjpe_mm"] <= 0.05, rep["d_pa_mpjpe_mm"]                      # PA-MPJPE: the bar, outright, every capture
+    assert rep["d_mpjpe_mm"] <= max(0.05, envelope["p1"]), (rep["d_mpjpe_mm"], envelope)
+    # per pose, against the fp64 arbiter: no farther from exact arithmetic than the reference's own fp32 run (x1.5)
+    if arb is not None:
+        for key in ("p1", "p2"):
+            h, r = arb[key]["hip_vs_ref64_mm"], arb[key]["ref32_vs_ref64_mm"]
+            assert h["median"] <= 1.5 * r["median"] + 0.02 and h["p90"] <= 1.5 * r["p90"] + 0.02, (key, h, r)
 
 
 def test_run_opt_main_and_inference_synthetic(tmp_path, math_mode):

@@ -358,6 +358,10 @@ template <int M>
 __device__ __forceinline__ float swz_xor(float v) {
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (M << 10) | 0x1F));
 }
+template <int C>      // every lane of a 32-lane group reads lane C of its group (and-mask 0, or-mask C)
+__device__ __forceinline__ float bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (C << 5)));
+}
 __device__ __forceinline__ float half_sum(float v) {
     v = v + swz_xor<16>(v);
     v = v + swz_xor<8>(v);
@@ -419,6 +423,8 @@ __global__ __launch_bounds__(64) void ipo_kernel(const float *__restrict__ x0, c
         qk = AdamP{stp[3], stp[8], stp[13]}; sc = AdamP{stp[4], stp[9], stp[14]};
     }
     double b1p = b1p0, b2p = b2p0;
+    // parameter c's (value, exp_avg, exp_avg_sq) live in lane c of the half-wave; lanes >= 5 carry a dummy
+    AdamP mine = jl == 0 ? qr : jl == 1 ? qi : jl == 2 ? qj : jl == 3 ? qk : sc;
     for (int it = 0; it < iters; ++it) {
         const float r = qr.p, i = qi.p, j = qj.p, kk = qk.p;
         const float n2 = r * r + i * i + j * j + kk * kk;
@@ -463,12 +469,22 @@ __global__ __launch_bounds__(64) void ipo_kernel(const float *__restrict__ x0, c
         float step_size, bc2s;
         if (ta < IPO_TABLE) { step_size = c_adam_step[ta]; bc2s = c_adam_bc2s[ta]; }
         else { step_size = (float)(0.1 / (1.0 - b1p)); bc2s = (float)sqrt(1.0 - b2p); }
-        qr.step(gr, step_size, bc2s);
-        if (ax) qi.step(gi, step_size, bc2s);
-        if (ay) qj.step(gj, step_size, bc2s);
-        if (az) qk.step(gk, step_size, bc2s);
-        sc.step(gs, step_size, bc2s);
+        // The five Adam updates are the same statements on different data: lane c of the half-wave (c = 0..4 <-> rot_vect,
+        // x, y, z, scale) carries parameter c's moments and takes its step, the new value is broadcast back (ds_swizzle
+        // with and-mask 0: every lane of the 32-lane group reads lane c).  One update's IEEE sqrt and two divisions per
+        // iteration instead of five - the same operations on the same values as updating all five in every lane.
+        {
+            const float g_c = jl == 0 ? gr : jl == 1 ? gi : jl == 2 ? gj : jl == 3 ? gk : gs;
+            const bool upd = jl == 0 || (jl == 1 && ax) || (jl == 2 && ay) || (jl == 3 && az) || jl == 4;
+            AdamP nxt = mine;
+            nxt.step(g_c, step_size, bc2s);
+            if (upd) mine = nxt;
+            qr.p = bcast<0>(mine.p); qi.p = bcast<1>(mine.p); qj.p = bcast<2>(mine.p); qk.p = bcast<3>(mine.p); sc.p = bcast<4>(mine.p);
+        }
     }
+    // moments back from their lanes (the state record / resume interface is per row)
+    qr.m = bcast<0>(mine.m); qi.m = bcast<1>(mine.m); qj.m = bcast<2>(mine.m); qk.m = bcast<3>(mine.m); sc.m = bcast<4>(mine.m);
+    qr.v = bcast<0>(mine.v); qi.v = bcast<1>(mine.v); qj.v = bcast<2>(mine.v); qk.v = bcast<3>(mine.v); sc.v = bcast<4>(mine.v);
     if (row_ok && jl == 0) {
         const float r = qr.p, i = qi.p, j = qj.p, kk = qk.p;
         const float ts = 2.0f / (r * r + i * i + j * j + kk * kk);
