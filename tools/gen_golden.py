@@ -816,6 +816,24 @@ def _driver_full_size(tag, N, H, S, seed_pose, seed_cl, keylist, ipo_T, minT, co
     os.makedirs(cache_dir, exist_ok=True)
     batch_results, ang, scl, loss, cs_all, T_all = [], [], [], [], [], []
     import time
+    if os.environ.get("ZEDO_GOLDEN_FILL") == "reverse":
+        # helper process: fill the per-hypothesis cache from the LAST hypothesis downwards and stop - a second core for a
+        # capture another process is running forwards (it finds the finished hypotheses in the cache when it gets there)
+        for sid in reversed(range(H)):
+            f = os.path.join(cache_dir, f"{tag}_h{sid:02d}.npz")
+            if os.path.exists(f) or os.path.exists(f + ".claim"):
+                continue
+            open(f + ".claim", "w").close()
+            t0 = time.time()
+            noisy = (torch.ones((N, 17, 3)) * torch.tensor(cl - cl[:, 0:1, :])[sid:sid + 1]).to(dtype)
+            r = run_ref_ipo(noisy.numpy(), gt_2d[:, :, :2], K, "z", keylist, ipo_T, minT, 2.0, 500, trace_upto=1, dtype=dtype)
+            x = torch.tensor(r["R"]).bmm(noisy.permute(0, 2, 1)).permute(0, 2, 1).contiguous().numpy()
+            res, _, _ = run_ref_oil(m, x, gt_2d[:, :, :2], gt_2d[:, :, 2].copy(), K, r["T"], S, [], dtype)
+            np.savez(f + ".tmp.npz", res=res, R=r["R"], T=r["T"], T0=r["T0"], loss=r["loss"])
+            os.replace(f + ".tmp.npz", f)
+            os.remove(f + ".claim")
+            print(f"  {tag}: (helper) hypothesis {sid + 1}/{H} in {time.time() - t0:.0f} s", flush=True)
+        return
     for sid in range(H):
         f = os.path.join(cache_dir, f"{tag}_h{sid:02d}.npz")
         if os.path.exists(f):

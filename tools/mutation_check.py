@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sensitivity of the GPU parity suite: five one-line arithmetic mutations of the HIP path, each of which must turn
+"""Sensitivity of the GPU parity suite: seven one-line arithmetic mutations of the HIP path, each of which must turn
 at least one `-m gpu` test red (run on the GPU box from the repo root: `python tools/mutation_check.py [out.txt]`).
 
 Each mutant is the product library built with ONE extra -D flag (the hooks are `#ifdef ZEDO_MUT_*` lines in csrc/,
@@ -21,6 +21,9 @@ MUTANTS = [
     ("ZEDO_MUT_CONF2", "least-squares weight conf^4 -> conf^2 (zedo_geom.hip; simple_zeroshot_opt.py:85-88)"),
     ("ZEDO_MUT_SWITCH", "switch to the least-squares T one iteration late (zedo_capi.hip; run/opt_main.py:203-206)"),
     ("ZEDO_MUT_ARGMIN_TIE", "arg-min ties to the HIGHER hypothesis index (zedo_metric.hip; np.argmin, h36m.py:412)"),
+    # round 4: the rewritten IPO kernel and the split post_dense of small batches
+    ("ZEDO_MUT_IPO_JOINT", "IPO: the 17th key joint (lane 16 of the half-wave) drops out of the gradient sums (zedo_geom.hip; opt_main.py:189-191)"),
+    ("ZEDO_MUT_POST_Q3", "post_dense of batches <= 2048 rows: the fourth K quarter is read from the third (zedo_geom.hip post_reduce_kernel)"),
 ]
 
 
@@ -34,8 +37,10 @@ def build(flag):
 
 def run_suite():
     t0 = time.time()
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests", "-m", "gpu", "-q", "--no-header", "-rf", "-p", "no:cacheprovider"],
-                       cwd=ROOT, capture_output=True, text=True)
+    cmd = [sys.executable, "-m", "pytest", "tests", "-m", "gpu", "-q", "--no-header", "-rf", "-p", "no:cacheprovider"]
+    if os.environ.get("ZEDO_MUT_DESELECT"):          # e.g. the three-minute end-to-end ensembles: "not lie_inside and not pooled"
+        cmd += ["-k", os.environ["ZEDO_MUT_DESELECT"]]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
     out = r.stdout + r.stderr
     failed = sorted(set(re.findall(r"^FAILED (\S+)", out, re.M)))
     m = re.search(r"(\d+) passed", out)

@@ -239,7 +239,11 @@ __global__ __launch_bounds__(64) void post_reduce_kernel(float *__restrict__ xpa
             const f32x4 q0 = *reinterpret_cast<const f32x4 *>(p0 + v * 4);
             const f32x4 q1 = *reinterpret_cast<const f32x4 *>(p0 + 32 * XLD + v * 4);
             const f32x4 q2 = *reinterpret_cast<const f32x4 *>(p0 + 2 * 32 * XLD + v * 4);
+#ifdef ZEDO_MUT_POST_Q3       // tools/mutation_check.py only
+            const f32x4 q3 = q2;
+#else
             const f32x4 q3 = *reinterpret_cast<const f32x4 *>(p0 + 3 * 32 * XLD + v * 4);
+#endif
             const f32x4 bb = *reinterpret_cast<const f32x4 *>(sb + v * 4);
             f32x4 x4 = {0.f, 0.f, 0.f, 0.f};
             if (sde) x4 = *reinterpret_cast<const f32x4 *>(xr + v * 4);
@@ -392,7 +396,11 @@ __global__ __launch_bounds__(64) void ipo_kernel(const float *__restrict__ x0, c
     const int b_raw = blockIdx.x * 2 + (lane >> 5);
     const bool row_ok = b_raw < B;
     const int b = row_ok ? b_raw : B - 1;     // a half-wave without a row shadows the last row (uniform control flow) and stores nothing
+#ifdef ZEDO_MUT_IPO_JOINT     // tools/mutation_check.py only: the last joint of a 17-joint key list is lost
+    const bool jact = jl < k && jl < 16;
+#else
     const bool jact = jl < k;
+#endif
     const long long gb = row_offset + b;
     const int n = (int)(gb % N), h = (int)(gb / N);
     const int jn = s_kl[jl];
