@@ -355,23 +355,30 @@ struct IpoKeys { int j[IPO_KMAX]; };   // IPO_keylist travels as a kernel argume
 __constant__ float c_adam_step[IPO_TABLE];
 __constant__ float c_adam_bc2s[IPO_TABLE];
 
-// Sum over the 32 lanes of a half-wave in ONE fixed order, the xor butterfly 16, 8, 4, 2, 1 (ds_swizzle in bit-mask mode:
-// a cross-lane move inside 32-lane groups that touches no LDS memory).  Addition commutes, so both partners of a pair
-// form the same bits and all 32 lanes end with the same value: the optimiser state stays replicated without a broadcast.
+// Sum over the 32 lanes of a half-wave in ONE fixed order: four pairing levels inside each 16-lane row as DPP operand
+// modifiers of the add itself (row_mirror: i <-> 15 - i, row_half_mirror: i <-> 7 - i, quad_perm xor 2, quad_perm xor 1 - no
+// cross-lane instruction, no LDS-pipe latency), then the two rows of the half-wave by one ds_swizzle (xor 16).  Every level
+// pairs lanes SYMMETRICALLY and addition commutes, so both partners form the same bits and all 32 lanes end with the same
+// value: the optimiser state stays replicated without a broadcast.  (First version of round 4: five ds_swizzle levels -
+// 50 LDS-pipe round trips per iteration were most of the iteration's latency.)
 template <int M>
 __device__ __forceinline__ float swz_xor(float v) {
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (M << 10) | 0x1F));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
 template <int C>      // every lane of a 32-lane group reads lane C of its group (and-mask 0, or-mask C)
 __device__ __forceinline__ float bcast(float v) {
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (C << 5)));
 }
 __device__ __forceinline__ float half_sum(float v) {
+    v = v + dpp<0x140>(v);      // row_mirror
+    v = v + dpp<0x141>(v);      // row_half_mirror
+    v = v + dpp<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = v + dpp<0xB1>(v);       // quad_perm [1,0,3,2]
     v = v + swz_xor<16>(v);
-    v = v + swz_xor<8>(v);
-    v = v + swz_xor<4>(v);
-    v = v + swz_xor<2>(v);
-    v = v + swz_xor<1>(v);
     return v;
 }
 
