@@ -206,7 +206,8 @@ def test_pooled_over_the_three_draws(math_mode):
             k += 1
         diffs.append(e.mean() - np.mean(refs))
         s = e.std(ddof=1)
-        var += s ** 2 / len(e) + s ** 2 / len(refs)          # the reference's member spread taken equal to the kernels' (measured: it is)
+        s_ref = float(np.std(refs, ddof=1)) if len(refs) >= 3 else s      # its own member spread where it has members, else the kernels' (measured equal)
+        var += s ** 2 / len(e) + s_ref ** 2 / len(refs)
     pooled, se = float(np.mean(diffs)), float(np.sqrt(var) / len(DRAWS))
     _report({"test": "end_to_end_ensemble_pooled", "math": math_mode, "per_draw_mean_diff_mm": [float(d) for d in diffs], "pooled_mm": pooled,
              "standard_error_mm": se})

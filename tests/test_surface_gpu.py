@@ -354,9 +354,19 @@ def test_fused_driver_at_baseline_size_matches_reference(weights0, golden, name)
     # The round-3 clause "|mean delta| <= 3 standard errors" is gone; the distributional side is tests/test_ensemble_gpu.py.
     envelope = {"p1": 0.0, "p2": 0.0}
     if not h36m:
-        runs = [golden("driver_pw3d_full")] + [golden(f"driver_pw3d_full_env{k}") for k in range(1, 5)]
-        envelope = {"p1": (max(float(r["mpjpe"]) for r in runs) - min(float(r["mpjpe"]) for r in runs)) * 1e3,
-                    "p2": (max(float(r["pa_mpjpe"]) for r in runs) - min(float(r["pa_mpjpe"]) for r in runs)) * 1e3}
+        def runs_of(tag):
+            r, k = [golden(tag)], 1
+            while os.path.exists(os.path.join(ROOT, "tests", "golden", f"{tag}_env{k}.npz")):
+                r.append(golden(f"{tag}_env{k}"))
+                k += 1
+            return r
+        spread = lambda rs, key: (max(float(r[key]) for r in rs) - min(float(r[key]) for r in rs)) * 1e3
+        # the capture's own members where it has at least two of them, and never less than draw A's five-run envelope: all
+        # configs[2] draws share shape and settings
+        own, base = runs_of(name), runs_of("driver_pw3d_full")
+        assert len(base) >= 5, "tests/golden/driver_pw3d_full_env{1..4}.npz are missing"
+        envelope = {"p1": max(spread(base, "mpjpe"), spread(own, "mpjpe") if len(own) >= 3 else 0.0),
+                    "p2": max(spread(base, "pa_mpjpe"), spread(own, "pa_mpjpe") if len(own) >= 3 else 0.0)}
     with open("gpurun_out/parity_report.jsonl", "a") as f:
         f.write(json.dumps({"test": name + "_envelope", "d_mpjpe_mm": rep["d_mpjpe_mm"], "d_pa_mpjpe_mm": rep["d_pa_mpjpe_mm"],
                             "reference_self_envelope_mm": envelope}) + "\n")

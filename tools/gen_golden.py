@@ -955,7 +955,10 @@ def gen_driver_pw3d_full_env():
         ZEDO_ENV_RUN=3 ZEDO_GOLDEN_THREADS=1 python tools/gen_golden.py --only driver_pw3d_full_env"""
     run = int(os.environ["ZEDO_ENV_RUN"])
     assert run > 0
-    _driver_full_size(f"driver_pw3d_full_env{run}", 1015, 50, 1000, 103, 19, list(range(17)), 8.0, 0.2, "uniform", "3dpw", CACHE,
+    draw = os.environ.get("ZEDO_ENV_DRAW", "a")          # a | b | c: which configs[2] capture (default: driver_pw3d_full)
+    tag, seed_pose, seed_cl, conf_mode = {"a": ("driver_pw3d_full", 103, 19, "uniform"), "b": ("driver_pw3d_full_b", 203, 29, "ones"),
+                                          "c": ("driver_pw3d_full_c", 307, 31, "uniform")}[draw]
+    _driver_full_size(f"{tag}_env{run}", 1015, 50, 1000, seed_pose, seed_cl, list(range(17)), 8.0, 0.2, conf_mode, "3dpw", CACHE,
                       perturb=run)
 
 
