@@ -112,7 +112,7 @@ def test_ipo_end_state_distribution_matches_the_references(W, math_mode, name):
     reprojection loss over the 50 750 (hypothesis, pose) fits - ensemble mean of 12 HIP members against the ensemble mean of
     the reference's members, tolerance per quantile = 8 x the pooled single-member standard deviation of the two ensembles
     (floors 2e-4 rad / 1e-5 / 2e-4 px where a quantile does not move at all), i.e. TAKEN FROM THE ENSEMBLES.  Measured:
-    <= 4.8 (angle), 1.1 (scale), 6.0 (loss) such deviations; in absolute terms 6e-3 rad, 1.4e-3, 1.3e-2 px of 43."""
+    <= 5.5 (angle), 1.6 (scale), 6.2 (loss) such deviations; in absolute terms 5.1e-3 rad, 1.5e-3, 1.3e-2 px of 43."""
     if math_mode != "f32":
         pytest.skip("the IPO kernel does not depend on the arithmetic mode of the dense layers: covered by the f32 session")
     dr = Draw(name)
@@ -133,7 +133,7 @@ def test_ipo_end_state_distribution_matches_the_references(W, math_mode, name):
     rec["mean_loss_px"] = dict(ref=float(ref["mean_loss"].mean()), hip=float(hip["mean_loss"].mean()), diff=dm,
                                member_sd_ref=float(ref["mean_loss"].std(ddof=1)), member_sd_hip=float(hip["mean_loss"].std(ddof=1)))
     _report(rec)
-    assert abs(dm) <= 3e-3, rec["mean_loss_px"]                  # of ~43 px: 7e-5 relative (measured <= 1.2e-3)
+    assert abs(dm) <= 3e-3, rec["mean_loss_px"]                  # of ~43 px: 7e-5 relative (measured <= 1.5e-3)
 
 
 def _members(name, math_mode):

@@ -313,6 +313,52 @@ def test_ipo_trajectory_golden(zh, golden, N, axes, kname):
     np.testing.assert_allclose(Rn, O.quaternion_to_matrix(q.cpu().numpy()), atol=1e-6, rtol=0)
 
 
+IPO_TWINS = r"""
+import hashlib, json, os, sys
+import numpy as np
+root = %r
+sys.path.insert(0, os.path.join(root, "zedo-release_amd"))
+import torch
+import zedo_hip as zh
+from lib.dataset import synthetic as syn
+out = {}
+for tag, kl, ipoT, minT, N, H in (("pw3d", list(range(17)), 8.0, 0.2, 301, 3), ("h36m", [0, 1, 4], 3.0, 0.5, 257, 2)):
+    d = syn.make_poses(N, seed=5, conf_mode="uniform")
+    cl = syn.make_clusters(H, seed=5)
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+    x0 = dev(cl - cl[:, 0:1])
+    for axes in ("z", "xyz"):
+        R, T, q, sc = zh.ipo_fit(x0, dev(d["db_2d"][:, :, :2]), dev(d["camera_param"]), kl, axes, ipoT, minT, 2.0, 500, N * len(kl) * 2, H * N, return_params=True)
+        h = hashlib.sha256()
+        for t in (R, T, q, sc):
+            h.update(t.cpu().numpy().tobytes())
+        out[tag + "_" + axes] = h.hexdigest()
+        assert bool(torch.isfinite(R).all())
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_ipo_kernels_are_bitwise_twins():
+    """The IPO has two kernels - one row per half-wave with a joint per lane (small batches: latency), one lane per row
+    (batches that fill the chip: throughput) - chosen by the LOCAL row count.  That is only legitimate if a row's fit does
+    not depend on the choice: both are pinned (ZEDO_IPO_KERNEL=half|row, read once per process) on the same problems - the
+    17-joint and the 3-joint key list, z and xyz axes, 500 iterations - and must agree BIT FOR BIT in R, T, q and scale."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for pin in ("half", "row"):
+        e = dict(os.environ)
+        e["ZEDO_IPO_KERNEL"] = pin
+        r = subprocess.run([sys.executable, "-c", IPO_TWINS % root], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+        res[pin] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["half"] == res["row"], (res["half"], res["row"])
+
+
+
 @pytest.mark.parametrize("N,axes,kname", IPO_CASES)
 def test_ipo_single_iterations_from_reference_state(zh, golden, N, axes, kname):
     """Every one of the first 50 Adam iterations, taken on its own from the REFERENCE's optimiser state.

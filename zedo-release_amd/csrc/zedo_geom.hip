@@ -5,6 +5,7 @@
 #include "zedo_internal.h"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace zedo {
 
@@ -382,12 +383,100 @@ __device__ __forceinline__ float half_sum(float v) {
     return v;
 }
 
+// ---- pieces shared by the two IPO kernels (the SAME statements, so that both produce the same bits) -------------------
+struct IpoRot { float R00, R01, R02, R10, R11, R12, R20, R21, R22, Tx, Ty, Tz, ts; };
+
+// R = I + ts * Q(q) (quaternion_to_matrix, utils.py:59-88) and T = T0 * clamp(scale) (simple_zeroshot_opt.py:26-31)
+__device__ __forceinline__ IpoRot ipo_rot(float r, float i, float j, float kk, float scp, float min_s, float max_s, const float (&T0)[3]) {
+    IpoRot o;
+    const float n2 = r * r + i * i + j * j + kk * kk;
+    const float ts = 2.0f / n2;
+    o.ts = ts;
+    o.R00 = 1.f - ts * (j * j + kk * kk); o.R01 = ts * (i * j - kk * r); o.R02 = ts * (i * kk + j * r);
+    o.R10 = ts * (i * j + kk * r); o.R11 = 1.f - ts * (i * i + kk * kk); o.R12 = ts * (j * kk - i * r);
+    o.R20 = ts * (i * kk - j * r); o.R21 = ts * (j * kk + i * r); o.R22 = 1.f - ts * (i * i + j * j);
+    const float scc = fminf(fmaxf(scp, min_s), max_s);
+    o.Tx = T0[0] * scc; o.Ty = T0[1] * scc; o.Tz = T0[2] * scc;
+    return o;
+}
+
+// One key joint: forward, L1 sign, backward to the camera-frame point; its ten contributions to the gradient sums
+// t[0] -> d/d scale, t[1..9] -> G00 G01 G02 G10 G11 G12 G20 G21 G22 (G = sum_j g_p x^T)
+__device__ __forceinline__ void ipo_joint_terms(const float (&K)[9], const float (&T0)[3], const IpoRot &o, float x, float y, float z,
+                                                float cu, float cv, float inv_norm, float (&t)[10]) {
+    const float px = o.R00 * x + o.R01 * y + o.R02 * z + o.Tx;
+    const float py = o.R10 * x + o.R11 * y + o.R12 * z + o.Ty;
+    const float pz = o.R20 * x + o.R21 * y + o.R22 * z + o.Tz;
+    const float w0 = K[0] * px + K[1] * py + K[2] * pz;
+    const float w1 = K[3] * px + K[4] * py + K[5] * pz;
+    const float w2 = K[6] * px + K[7] * py + K[8] * pz;
+    const float gu = sgnf(w0 / w2 - cu) * inv_norm;   // d mean|e| / du
+    const float gv = sgnf(w1 / w2 - cv) * inv_norm;
+    const float gw0 = gu / w2, gw1 = gv / w2;
+    const float gw2 = -gu * ((w0 / w2) / w2) - gv * ((w1 / w2) / w2);  // torch div backward form
+    const float gpx = K[0] * gw0 + K[3] * gw1 + K[6] * gw2;       // K^T g_w
+    const float gpy = K[1] * gw0 + K[4] * gw1 + K[7] * gw2;
+    const float gpz = K[2] * gw0 + K[5] * gw1 + K[8] * gw2;
+    t[0] = gpx * T0[0] + gpy * T0[1] + gpz * T0[2];
+    t[1] = gpx * x; t[2] = gpx * y; t[3] = gpx * z;
+    t[4] = gpy * x; t[5] = gpy * y; t[6] = gpy * z;
+    t[7] = gpz * x; t[8] = gpz * y; t[9] = gpz * z;
+}
+
+// gradients of the four quaternion components from the summed G (dL/d two_s = <G, Q>, d two_s / d q_c = -two_s^2 q_c)
+__device__ __forceinline__ void ipo_quat_grads(const float (&S)[10], float r, float i, float j, float kk, float ts, float &gr, float &gi,
+                                               float &gj, float &gk) {
+    const float G00 = S[1], G01 = S[2], G02 = S[3], G10 = S[4], G11 = S[5], G12 = S[6], G20 = S[7], G21 = S[8], G22 = S[9];
+    const float gts = G00 * -(j * j + kk * kk) + G01 * (i * j - kk * r) + G02 * (i * kk + j * r) +
+                      G10 * (i * j + kk * r) + G11 * -(i * i + kk * kk) + G12 * (j * kk - i * r) +
+                      G20 * (i * kk - j * r) + G21 * (j * kk + i * r) + G22 * -(i * i + j * j);
+    const float dts = -gts * ts * ts;
+    gr = ts * (-G01 * kk + G02 * j + G10 * kk - G12 * i - G20 * j + G21 * i) + dts * r;
+    gi = ts * (G01 * j + G02 * kk + G10 * j - 2.f * G11 * i - G12 * r + G20 * kk + G21 * r - 2.f * G22 * i) + dts * i;
+    gj = ts * (-2.f * G00 * j + G01 * i + G02 * r + G10 * i + G12 * kk - G20 * r + G21 * kk - 2.f * G22 * j) + dts * j;
+    gk = ts * (-2.f * G00 * kk - G01 * r + G02 * i + G10 * r - 2.f * G11 * kk + G12 * j + G20 * i + G21 * j) + dts * kk;
+}
+
+// T0 = ipo_T * normalise(Kinv [u0 v0 1])  (opt_main.py:177-179); joint 0 is the pelvis
+__device__ __forceinline__ void ipo_T0(const float (&K)[9], double u, double v, float ipo_T, float (&T0)[3]) {
+    double Ki[9];
+    inv3x3(K, Ki);
+    const double tx = Ki[0] * u + Ki[1] * v + Ki[2], ty = Ki[3] * u + Ki[4] * v + Ki[5], tz = Ki[6] * u + Ki[7] * v + Ki[8];
+    const double in = (double)ipo_T / sqrt(tx * tx + ty * ty + tz * tz);
+    T0[0] = (float)(tx * in); T0[1] = (float)(ty * in); T0[2] = (float)(tz * in);
+}
+
+__device__ __forceinline__ void ipo_adam_terms(int ta, double &b1p, double &b2p, float &step_size, float &bc2s) {
+    b1p *= 0.9; b2p *= 0.999;
+    if (ta < IPO_TABLE) { step_size = c_adam_step[ta]; bc2s = c_adam_bc2s[ta]; }
+    else { step_size = (float)(0.1 / (1.0 - b1p)); bc2s = (float)sqrt(1.0 - b2p); }
+}
+
+__device__ __forceinline__ void ipo_store(const AdamP &qr, const AdamP &qi, const AdamP &qj, const AdamP &qk, const AdamP &sc, const float (&T0)[3],
+                                          float min_s, float max_s, int b, float *Rout, float *Tout, float *qout, float *sout, float *stp) {
+    const float r = qr.p, i = qi.p, j = qj.p, kk = qk.p;
+    const float ts = 2.0f / (r * r + i * i + j * j + kk * kk);
+    float *Ro = Rout + (size_t)b * 9;
+    Ro[0] = 1.f - ts * (j * j + kk * kk); Ro[1] = ts * (i * j - kk * r); Ro[2] = ts * (i * kk + j * r);
+    Ro[3] = ts * (i * j + kk * r); Ro[4] = 1.f - ts * (i * i + kk * kk); Ro[5] = ts * (j * kk - i * r);
+    Ro[6] = ts * (i * kk - j * r); Ro[7] = ts * (j * kk + i * r); Ro[8] = 1.f - ts * (i * i + j * j);
+    const float scc = fminf(fmaxf(sc.p, min_s), max_s);
+    Tout[(size_t)b * 3] = T0[0] * scc; Tout[(size_t)b * 3 + 1] = T0[1] * scc; Tout[(size_t)b * 3 + 2] = T0[2] * scc;
+    if (qout) { qout[(size_t)b * 4] = r; qout[(size_t)b * 4 + 1] = i; qout[(size_t)b * 4 + 2] = j; qout[(size_t)b * 4 + 3] = kk; }
+    if (sout) sout[b] = sc.p;
+    if (stp) {
+        stp[0] = qr.p; stp[1] = qi.p; stp[2] = qj.p; stp[3] = qk.p; stp[4] = sc.p;
+        stp[5] = qr.m; stp[6] = qi.m; stp[7] = qj.m; stp[8] = qk.m; stp[9] = sc.m;
+        stp[10] = qr.v; stp[11] = qi.v; stp[12] = qj.v; stp[13] = qk.v; stp[14] = sc.v;
+    }
+}
+
 // One pose-hypothesis row per 32-lane HALF-WAVE, one key joint per lane (k <= 17 of the 32 lanes carry a joint, the
 // others contribute exact zeros): an iteration is one joint's forward / backward (~190 instructions with its six IEEE
-// divisions) + ten half-wave sums + the Adam update, instead of k joints in sequence on one lane - the 500-iteration
-// chain of the reference's 17-joint 3DPW key list shortens ~8x (3.2 ms -> 0.4 ms for any batch that does not fill the
-// chip; a full 50 750-row batch, 0.1 % of whose pass is this kernel, runs it throughput-bound at about the old cost).
-// The sums over joints have ONE order (half_sum) whatever the batch, shard or launch: rows are bit-identical across them.
+// divisions) + ten half-wave sums + one Adam update, instead of k joints in sequence on one lane - the 500-iteration
+// chain of the reference's 17-joint 3DPW key list shortens ~6x (3.2 ms -> 0.49 ms for any batch that does not fill the
+// chip).  Large batches run ipo_row_kernel below: the same statements and the same pairing tree on one lane per row.
+// The sums over joints have ONE order (half_sum) whatever the batch, shard, launch or kernel: rows are bit-identical.
 __global__ __launch_bounds__(64) void ipo_kernel(const float *__restrict__ x0, const float *__restrict__ uv,
                                                   const float *__restrict__ Kmat, const IpoKeys keylist,
                                                   int k, int axes_mask, float ipo_T, float min_s, float max_s,
@@ -412,22 +501,13 @@ __global__ __launch_bounds__(64) void ipo_kernel(const float *__restrict__ x0, c
     const int n = (int)(gb % N), h = (int)(gb / N);
     const int jn = s_kl[jl];
     const float *xh = x0 + ((size_t)h * J + jn) * 3;
-    const float x = jact ? xh[0] : 0.f, y = jact ? xh[1] : 0.f, z = jact ? xh[2] : 0.f;
+    const float x = xh[0], y = xh[1], z = xh[2];
     const float cu = uv[((size_t)n * J + jn) * 2], cv = uv[((size_t)n * J + jn) * 2 + 1];
     float K[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) K[i] = Kmat[(size_t)n * 9 + i];
-    // T0 = ipo_T * normalise(Kinv [u0 v0 1])  (opt_main.py:177-179); joint 0 is the pelvis
     float T0[3];
-    {
-        double Ki[9];
-        inv3x3(K, Ki);
-        const double u = uv[(size_t)n * J * 2], v = uv[(size_t)n * J * 2 + 1];
-        const double tx = Ki[0] * u + Ki[1] * v + Ki[2], ty = Ki[3] * u + Ki[4] * v + Ki[5],
-                     tz = Ki[6] * u + Ki[7] * v + Ki[8];
-        const double in = (double)ipo_T / sqrt(tx * tx + ty * ty + tz * tz);
-        T0[0] = (float)(tx * in); T0[1] = (float)(ty * in); T0[2] = (float)(tz * in);
-    }
+    ipo_T0(K, uv[(size_t)n * J * 2], uv[(size_t)n * J * 2 + 1], ipo_T, T0);
     AdamP qr{1.f, 0.f, 0.f}, qi{0.f, 0.f, 0.f}, qj{0.f, 0.f, 0.f}, qk{0.f, 0.f, 0.f}, sc{1.f, 0.f, 0.f};
     const bool ax = axes_mask & 1, ay = axes_mask & 2, az = axes_mask & 4;
     // resumable fit: state[b] = (p[5], exp_avg[5], exp_avg_sq[5]) in the order (rot_vect, x, y, z, scale) after
@@ -439,51 +519,22 @@ __global__ __launch_bounds__(64) void ipo_kernel(const float *__restrict__ x0, c
     }
     double b1p = b1p0, b2p = b2p0;
     // parameter c's (value, exp_avg, exp_avg_sq) live in lane c of the half-wave; lanes >= 5 carry a dummy
-    AdamP mine = jl == 0 ? qr : jl == 1 ? qi : jl == 2 ? qj : jl == 3 ? qk : sc;
+    AdamP mine;
+    mine.p = jl == 0 ? qr.p : jl == 1 ? qi.p : jl == 2 ? qj.p : jl == 3 ? qk.p : sc.p;
+    mine.m = jl == 0 ? qr.m : jl == 1 ? qi.m : jl == 2 ? qj.m : jl == 3 ? qk.m : sc.m;
+    mine.v = jl == 0 ? qr.v : jl == 1 ? qi.v : jl == 2 ? qj.v : jl == 3 ? qk.v : sc.v;
     for (int it = 0; it < iters; ++it) {
         const float r = qr.p, i = qi.p, j = qj.p, kk = qk.p;
-        const float n2 = r * r + i * i + j * j + kk * kk;
-        const float ts = 2.0f / n2;
-        // R = I + ts * Q(q)  (quaternion_to_matrix, utils.py:59-88)
-        const float R00 = 1.f - ts * (j * j + kk * kk), R01 = ts * (i * j - kk * r), R02 = ts * (i * kk + j * r);
-        const float R10 = ts * (i * j + kk * r), R11 = 1.f - ts * (i * i + kk * kk), R12 = ts * (j * kk - i * r);
-        const float R20 = ts * (i * kk - j * r), R21 = ts * (j * kk + i * r), R22 = 1.f - ts * (i * i + j * j);
-        const float scc = fminf(fmaxf(sc.p, min_s), max_s);
-        const float Tx = T0[0] * scc, Ty = T0[1] * scc, Tz = T0[2] * scc;
-        // this lane's joint: forward, L1 sign, backward to the camera-frame point (lanes without a joint: exact zeros)
-        const float px = R00 * x + R01 * y + R02 * z + Tx;
-        const float py = R10 * x + R11 * y + R12 * z + Ty;
-        const float pz = R20 * x + R21 * y + R22 * z + Tz;
-        const float w0 = K[0] * px + K[1] * py + K[2] * pz;
-        const float w1 = K[3] * px + K[4] * py + K[5] * pz;
-        const float w2 = K[6] * px + K[7] * py + K[8] * pz;
-        const float gu = sgnf(w0 / w2 - cu) * inv_norm;   // d mean|e| / du
-        const float gv = sgnf(w1 / w2 - cv) * inv_norm;
-        const float gw0 = gu / w2, gw1 = gv / w2;
-        const float gw2 = -gu * ((w0 / w2) / w2) - gv * ((w1 / w2) / w2);  // torch div backward form
-        float gpx = K[0] * gw0 + K[3] * gw1 + K[6] * gw2;       // K^T g_w
-        float gpy = K[1] * gw0 + K[4] * gw1 + K[7] * gw2;
-        float gpz = K[2] * gw0 + K[5] * gw1 + K[8] * gw2;
-        if (!jact) { gpx = 0.f; gpy = 0.f; gpz = 0.f; }
-        const float gsc = half_sum(gpx * T0[0] + gpy * T0[1] + gpz * T0[2]);
-        const float G00 = half_sum(gpx * x), G01 = half_sum(gpx * y), G02 = half_sum(gpx * z);
-        const float G10 = half_sum(gpy * x), G11 = half_sum(gpy * y), G12 = half_sum(gpy * z);
-        const float G20 = half_sum(gpz * x), G21 = half_sum(gpz * y), G22 = half_sum(gpz * z);
-        // dL/d two_s = <G, Q>
-        const float gts = G00 * -(j * j + kk * kk) + G01 * (i * j - kk * r) + G02 * (i * kk + j * r) +
-                          G10 * (i * j + kk * r) + G11 * -(i * i + kk * kk) + G12 * (j * kk - i * r) +
-                          G20 * (i * kk - j * r) + G21 * (j * kk + i * r) + G22 * -(i * i + j * j);
-        const float dts = -gts * ts * ts;  // d two_s / d q_c = -two_s^2 q_c
-        const float gr = ts * (-G01 * kk + G02 * j + G10 * kk - G12 * i - G20 * j + G21 * i) + dts * r;
-        const float gi = ts * (G01 * j + G02 * kk + G10 * j - 2.f * G11 * i - G12 * r + G20 * kk + G21 * r - 2.f * G22 * i) + dts * i;
-        const float gj = ts * (-2.f * G00 * j + G01 * i + G02 * r + G10 * i + G12 * kk - G20 * r + G21 * kk - 2.f * G22 * j) + dts * j;
-        const float gk = ts * (-2.f * G00 * kk - G01 * r + G02 * i + G10 * r - 2.f * G11 * kk + G12 * j + G20 * i + G21 * j) + dts * kk;
-        const float gs = (sc.p >= min_s && sc.p <= max_s) ? gsc : 0.f;   // clamp backward
-        b1p *= 0.9; b2p *= 0.999;
-        const int ta = it_begin + it;              // Adam's step count - 1
+        const IpoRot o = ipo_rot(r, i, j, kk, sc.p, min_s, max_s, T0);
+        float t[10], S[10];
+        ipo_joint_terms(K, T0, o, x, y, z, cu, cv, inv_norm, t);       // this lane's joint
+#pragma unroll
+        for (int e = 0; e < 10; ++e) S[e] = half_sum(jact ? t[e] : 0.f);   // lanes without a joint: exact +0
+        float gr, gi, gj, gk;
+        ipo_quat_grads(S, r, i, j, kk, o.ts, gr, gi, gj, gk);
+        const float gs = (sc.p >= min_s && sc.p <= max_s) ? S[0] : 0.f;   // clamp backward
         float step_size, bc2s;
-        if (ta < IPO_TABLE) { step_size = c_adam_step[ta]; bc2s = c_adam_bc2s[ta]; }
-        else { step_size = (float)(0.1 / (1.0 - b1p)); bc2s = (float)sqrt(1.0 - b2p); }
+        ipo_adam_terms(it_begin + it, b1p, b2p, step_size, bc2s);
         // The five Adam updates are the same statements on different data: lane c of the half-wave (c = 0..4 <-> rot_vect,
         // x, y, z, scale) carries parameter c's moments and takes its step, the new value is broadcast back (ds_swizzle
         // with and-mask 0: every lane of the 32-lane group reads lane c).  One update's IEEE sqrt and two divisions per
@@ -500,24 +551,119 @@ __global__ __launch_bounds__(64) void ipo_kernel(const float *__restrict__ x0, c
     // moments back from their lanes (the state record / resume interface is per row)
     qr.m = bcast<0>(mine.m); qi.m = bcast<1>(mine.m); qj.m = bcast<2>(mine.m); qk.m = bcast<3>(mine.m); sc.m = bcast<4>(mine.m);
     qr.v = bcast<0>(mine.v); qi.v = bcast<1>(mine.v); qj.v = bcast<2>(mine.v); qk.v = bcast<3>(mine.v); sc.v = bcast<4>(mine.v);
-    if (row_ok && jl == 0) {
-        const float r = qr.p, i = qi.p, j = qj.p, kk = qk.p;
-        const float ts = 2.0f / (r * r + i * i + j * j + kk * kk);
-        float *Ro = Rout + (size_t)b * 9;
-        Ro[0] = 1.f - ts * (j * j + kk * kk); Ro[1] = ts * (i * j - kk * r); Ro[2] = ts * (i * kk + j * r);
-        Ro[3] = ts * (i * j + kk * r); Ro[4] = 1.f - ts * (i * i + kk * kk); Ro[5] = ts * (j * kk - i * r);
-        Ro[6] = ts * (i * kk - j * r); Ro[7] = ts * (j * kk + i * r); Ro[8] = 1.f - ts * (i * i + j * j);
-        const float scc = fminf(fmaxf(sc.p, min_s), max_s);
-        Tout[(size_t)b * 3] = T0[0] * scc; Tout[(size_t)b * 3 + 1] = T0[1] * scc; Tout[(size_t)b * 3 + 2] = T0[2] * scc;
-        if (qout) { qout[(size_t)b * 4] = r; qout[(size_t)b * 4 + 1] = i; qout[(size_t)b * 4 + 2] = j; qout[(size_t)b * 4 + 3] = kk; }
-        if (sout) sout[b] = sc.p;
-        if (stp) {
-            const AdamP *all[5] = {&qr, &qi, &qj, &qk, &sc};
+    if (row_ok && jl == 0) ipo_store(qr, qi, qj, qk, sc, T0, min_s, max_s, b, Rout, Tout, qout, sout, stp);
+}
+
+// ---- the same fit on ONE LANE per row, for batches that fill the chip --------------------------------------------------
+// Above ~32 000 rows (17-joint key list; ~8 000 rows with the 3-joint list) the half-wave kernel is bound by VALU issue
+// and repeats every per-row statement in 32 lanes; here a lane walks its row's K key joints itself and combines their ten
+// terms in the pairing tree half_sum spells with cross-lane moves - slots 0..31, slot j = key joint j, exact +0 beyond K:
+//   a[i] = t[i] + t[15 - i], b[i] = a[i] + a[7 - i], c[i] = b[i] + b[i ^ 2], d = c[0] + c[1] per 16-slot row; sum = d(row 0) + d(row 1)
+// (what lanes 0 and 16 of a half-wave compute; every other lane computes the same bits, addition being commutative).
+// K is a template parameter (the shipped key lists: 3 and 17 joints) so that the tree unrolls over registers.
+constexpr int IPO_ROW_TB = 128;
+template <int KJ, int S>
+__device__ __forceinline__ void ipo_slot(const float (&K)[9], const float (&T0)[3], const IpoRot &o, const float (&x)[KJ], const float (&y)[KJ],
+                                         const float (&z)[KJ], const float *cu, const float *cv, float inv_norm, float (&t)[10]) {
+    if constexpr (S < KJ) {
+        ipo_joint_terms(K, T0, o, x[S], y[S], z[S], cu[S * IPO_ROW_TB], cv[S * IPO_ROW_TB], inv_norm, t);
+    } else {
 #pragma unroll
-            for (int c = 0; c < 5; ++c) { stp[c] = all[c]->p; stp[5 + c] = all[c]->m; stp[10 + c] = all[c]->v; }
-        }
+        for (int e = 0; e < 10; ++e) t[e] = 0.f;
     }
 }
+#define IPO_SLOT_ARGS K, T0, o, x, y, z, cu, cv, inv_norm
+#define IPO_SLOT_PARAMS const float (&K)[9], const float (&T0)[3], const IpoRot &o, const float (&x)[KJ], const float (&y)[KJ], \
+                        const float (&z)[KJ], const float *cu, const float *cv, float inv_norm
+template <int KJ, int BASE, int I>
+__device__ __forceinline__ void ipo_pair_a(IPO_SLOT_PARAMS, float (&a)[10]) {
+    float u[10], v[10];
+    ipo_slot<KJ, BASE + I>(IPO_SLOT_ARGS, u);
+    ipo_slot<KJ, BASE + 15 - I>(IPO_SLOT_ARGS, v);
+#pragma unroll
+    for (int e = 0; e < 10; ++e) a[e] = u[e] + v[e];
+}
+template <int KJ, int BASE, int I>
+__device__ __forceinline__ void ipo_pair_b(IPO_SLOT_PARAMS, float (&b)[10]) {
+    float u[10], v[10];
+    ipo_pair_a<KJ, BASE, I>(IPO_SLOT_ARGS, u);
+    ipo_pair_a<KJ, BASE, 7 - I>(IPO_SLOT_ARGS, v);
+#pragma unroll
+    for (int e = 0; e < 10; ++e) b[e] = u[e] + v[e];
+}
+template <int KJ, int BASE>
+__device__ __forceinline__ void ipo_row_sum(IPO_SLOT_PARAMS, float (&d)[10]) {
+    float b0[10], b1[10], b2[10], b3[10];
+    ipo_pair_b<KJ, BASE, 0>(IPO_SLOT_ARGS, b0);
+    ipo_pair_b<KJ, BASE, 2>(IPO_SLOT_ARGS, b2);
+#pragma unroll
+    for (int e = 0; e < 10; ++e) b0[e] = b0[e] + b2[e];                  // c[0]
+    ipo_pair_b<KJ, BASE, 1>(IPO_SLOT_ARGS, b1);
+    ipo_pair_b<KJ, BASE, 3>(IPO_SLOT_ARGS, b3);
+#pragma unroll
+    for (int e = 0; e < 10; ++e) d[e] = b0[e] + (b1[e] + b3[e]);         // c[0] + c[1]
+}
+
+template <int KJ>
+__global__ __launch_bounds__(IPO_ROW_TB) void ipo_row_kernel(const float *__restrict__ x0, const float *__restrict__ uv,
+                                                             const float *__restrict__ Kmat, const IpoKeys keylist, int axes_mask,
+                                                             float ipo_T, float min_s, float max_s, int iters, float inv_norm,
+                                                             float *__restrict__ Rout, float *__restrict__ Tout,
+                                                             float *__restrict__ qout, float *__restrict__ sout,
+                                                             float *__restrict__ state, int it_begin, double b1p0, double b2p0,
+                                                             int B, int N, int J, long long row_offset) {
+    __shared__ float s_cu[KJ][IPO_ROW_TB], s_cv[KJ][IPO_ROW_TB];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x * IPO_ROW_TB + tid;
+    if (b >= B) return;
+    const long long gb = row_offset + b;
+    const int n = (int)(gb % N), h = (int)(gb / N);
+    float x[KJ], y[KJ], z[KJ];
+#pragma unroll
+    for (int jj = 0; jj < KJ; ++jj) {
+        const int jn = keylist.j[jj];
+        const float *xh = x0 + ((size_t)h * J + jn) * 3;
+        x[jj] = xh[0]; y[jj] = xh[1]; z[jj] = xh[2];
+        s_cu[jj][tid] = uv[((size_t)n * J + jn) * 2];
+        s_cv[jj][tid] = uv[((size_t)n * J + jn) * 2 + 1];
+    }
+    const float *cu = &s_cu[0][tid], *cv = &s_cv[0][tid];
+    float K[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) K[i] = Kmat[(size_t)n * 9 + i];
+    float T0[3];
+    ipo_T0(K, uv[(size_t)n * J * 2], uv[(size_t)n * J * 2 + 1], ipo_T, T0);
+    AdamP qr{1.f, 0.f, 0.f}, qi{0.f, 0.f, 0.f}, qj{0.f, 0.f, 0.f}, qk{0.f, 0.f, 0.f}, sc{1.f, 0.f, 0.f};
+    const bool ax = axes_mask & 1, ay = axes_mask & 2, az = axes_mask & 4;
+    float *stp = state ? state + (size_t)b * 15 : nullptr;
+    if (stp && it_begin > 0) {
+        qr = AdamP{stp[0], stp[5], stp[10]}; qi = AdamP{stp[1], stp[6], stp[11]}; qj = AdamP{stp[2], stp[7], stp[12]};
+        qk = AdamP{stp[3], stp[8], stp[13]}; sc = AdamP{stp[4], stp[9], stp[14]};
+    }
+    double b1p = b1p0, b2p = b2p0;
+    for (int it = 0; it < iters; ++it) {
+        const float r = qr.p, i = qi.p, j = qj.p, kk = qk.p;
+        const IpoRot o = ipo_rot(r, i, j, kk, sc.p, min_s, max_s, T0);
+        float d0[10], d1[10], S[10];
+        ipo_row_sum<KJ, 0>(IPO_SLOT_ARGS, d0);
+        ipo_row_sum<KJ, 16>(IPO_SLOT_ARGS, d1);
+#pragma unroll
+        for (int e = 0; e < 10; ++e) S[e] = d0[e] + d1[e];
+        float gr, gi, gj, gk;
+        ipo_quat_grads(S, r, i, j, kk, o.ts, gr, gi, gj, gk);
+        const float gs = (sc.p >= min_s && sc.p <= max_s) ? S[0] : 0.f;   // clamp backward
+        float step_size, bc2s;
+        ipo_adam_terms(it_begin + it, b1p, b2p, step_size, bc2s);
+        qr.step(gr, step_size, bc2s);
+        if (ax) qi.step(gi, step_size, bc2s);
+        if (ay) qj.step(gj, step_size, bc2s);
+        if (az) qk.step(gk, step_size, bc2s);
+        sc.step(gs, step_size, bc2s);
+    }
+    ipo_store(qr, qi, qj, qk, sc, T0, min_s, max_s, b, Rout, Tout, qout, sout, stp);
+}
+#undef IPO_SLOT_ARGS
+#undef IPO_SLOT_PARAMS
 
 // the Adam table of this device, once (a blocking copy: the only synchronising step of the first fit on a device)
 static hipError_t ensure_adam_table() {
@@ -551,8 +697,27 @@ hipError_t launch_ipo_fit(const float *x0, const float *uv, const float *K, cons
     for (int i = 0; i < it_begin; ++i) { b1p0 *= 0.9; b2p0 *= 0.999; }   // the same running products the kernel forms
     IpoKeys keys{};
     for (int i = 0; i < k; ++i) keys.j[i] = h_keylist[i];
+    // Which kernel: the half-wave kernel (latency: 0.49 ms) until the batch fills the chip, the lane-per-row kernel above that
+    // (measured crossover: 17 joints ~32 000 rows, 3 joints ~8 000 rows).  Both produce the same bits (one pairing tree), so
+    // the choice may depend on the LOCAL row count without breaking shard invariance.  ZEDO_IPO_KERNEL=half|row pins it.
+    static const char *pin = getenv("ZEDO_IPO_KERNEL");
+    const bool has_row = (k == 3 || k == 17);
+    bool row = has_row && B >= (k == 17 ? 32768 : 8192);
+    if (pin && pin[0] == 'h') row = false;
+    if (pin && pin[0] == 'r' && has_row) row = true;
+    const float inv_norm = (float)(1.0 / normaliser);
+    if (row) {
+        const dim3 grid((B + IPO_ROW_TB - 1) / IPO_ROW_TB), block(IPO_ROW_TB);
+        if (k == 17)
+            hipLaunchKernelGGL(ipo_row_kernel<17>, grid, block, 0, st, x0, uv, K, keys, axes_mask, ipo_T, min_scale, max_scale, iters, inv_norm, R, T,
+                               q, scale, state, it_begin, b1p0, b2p0, B, N, J, row_offset);
+        else
+            hipLaunchKernelGGL(ipo_row_kernel<3>, grid, block, 0, st, x0, uv, K, keys, axes_mask, ipo_T, min_scale, max_scale, iters, inv_norm, R, T,
+                               q, scale, state, it_begin, b1p0, b2p0, B, N, J, row_offset);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(ipo_kernel, dim3((B + 1) / 2), dim3(64), 0, st, x0, uv, K, keys, k,
-                       axes_mask, ipo_T, min_scale, max_scale, iters, (float)(1.0 / normaliser), R, T, q, scale, state,
+                       axes_mask, ipo_T, min_scale, max_scale, iters, inv_norm, R, T, q, scale, state,
                        it_begin, b1p0, b2p0, B, N, J, row_offset);
     return hipGetLastError();
 }
