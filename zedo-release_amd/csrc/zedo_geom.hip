@@ -555,8 +555,8 @@ __global__ __launch_bounds__(64) void ipo_kernel(const float *__restrict__ x0, c
 }
 
 // ---- the same fit on ONE LANE per row, for batches that fill the chip --------------------------------------------------
-// Above ~32 000 rows (17-joint key list; ~8 000 rows with the 3-joint list) the half-wave kernel is bound by VALU issue
-// and repeats every per-row statement in 32 lanes; here a lane walks its row's K key joints itself and combines their ten
+// Above ~17 000 rows (17-joint key list; ~4 000 rows with the 3-joint list) the half-wave kernel, bound by VALU issue
+// and repeating every per-row statement in 32 lanes, is the slower one; here a lane walks its row's K key joints itself and combines their ten
 // terms in the pairing tree half_sum spells with cross-lane moves - slots 0..31, slot j = key joint j, exact +0 beyond K:
 //   a[i] = t[i] + t[15 - i], b[i] = a[i] + a[7 - i], c[i] = b[i] + b[i ^ 2], d = c[0] + c[1] per 16-slot row; sum = d(row 0) + d(row 1)
 // (what lanes 0 and 16 of a half-wave compute; every other lane computes the same bits, addition being commutative).
@@ -698,11 +698,12 @@ hipError_t launch_ipo_fit(const float *x0, const float *uv, const float *K, cons
     IpoKeys keys{};
     for (int i = 0; i < k; ++i) keys.j[i] = h_keylist[i];
     // Which kernel: the half-wave kernel (latency: 0.49 ms) until the batch fills the chip, the lane-per-row kernel above that
-    // (measured crossover: 17 joints ~32 000 rows, 3 joints ~8 000 rows).  Both produce the same bits (one pairing tree), so
+    // (measured, profiles/ipo_kernels_r04.txt: the half-wave kernel takes 0.49 ms up to ~2 000 rows and then grows by 0.13 ms per
+    // 1 000 rows whatever the key list; the row kernel takes 2.57 ms with 17 joints and 0.72 ms with 3 up to 65 536 rows).  Both produce the same bits (one pairing tree), so
     // the choice may depend on the LOCAL row count without breaking shard invariance.  ZEDO_IPO_KERNEL=half|row pins it.
     static const char *pin = getenv("ZEDO_IPO_KERNEL");
     const bool has_row = (k == 3 || k == 17);
-    bool row = has_row && B >= (k == 17 ? 32768 : 8192);
+    bool row = has_row && B >= (k == 17 ? 17408 : 4096);
     if (pin && pin[0] == 'h') row = false;
     if (pin && pin[0] == 'r' && has_row) row = true;
     const float inv_norm = (float)(1.0 / normaliser);
