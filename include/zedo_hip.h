@@ -161,7 +161,11 @@ int zedo_oil_run(const zedo_weights_t *w, const zedo_schedule_t *s, float *d_x, 
  * when rows are sharded).  d_x0 [H,J,3] (centred cluster poses), d_uv [N,J,2], d_K [N,3,3],
  * h_keylist[k] joint indices, axes_mask bit0=x bit1=y bit2=z.
  * Outputs: d_R [B,3,3], d_T [B,3] = T0*clamp(scale), optional d_q [B,4], d_scale [B] (may be NULL).
- * h_keylist is consumed before the call returns (it travels as a kernel argument); nothing synchronises.
+ * h_keylist is consumed before the call returns (it travels as a kernel argument); nothing synchronises, except the
+ * first fit of a process on a device (a blocking 16 KB copy of Adam's bias-correction terms to constant memory).
+ * The ten gradient sums over the key joints are formed in ONE fixed pairing order by both kernels behind this entry
+ * point (one row per half-wave for small batches, one lane per row for large ones): a row's result does not depend on B,
+ * row_offset, the shard it is in or the kernel that ran it.
  * H = number of hypotheses in d_x0: row_offset + B > H*N is rejected (ZEDO_E_BADARG).
  */
 int zedo_ipo_fit(const float *d_x0, const float *d_uv, const float *d_K, const int *h_keylist, int k,

@@ -52,7 +52,10 @@ def main():
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     rows, ok = [], True
     try:
+        only = os.environ.get("ZEDO_MUT_ONLY")          # e.g. ZEDO_MUT_ONLY=ZEDO_MUT_IPO_JOINT: one mutant (+ the clean rebuild)
         for flag, what in MUTANTS:
+            if only and flag != only:
+                continue
             build(flag)
             failed, passed, dt, out = run_suite()
             rows.append((flag, what, failed, passed, dt))

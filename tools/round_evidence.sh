@@ -27,4 +27,14 @@ for l in open("gpurun_out/config_shards_${TAG}.jsonl"):
     j = json.loads(l); print(j["config"]["rows_per_gpu"], j["ms_per_step"], j["value"], j["end_to_end_tflops"], (j["roofline"] or {}).get("frac"), (j.get("alt_mode") or {}).get("ms_per_step"))
 PY
 bash tools/profile_round.sh ${TAG} > gpurun_out/profile_round_${TAG}.log 2>&1
+# kernel traces of the small-batch configurations (configs[1]'s shape, configs[0])
+export TMPDIR=/tmp; R=$(pwd); cd /tmp; rm -rf /tmp/zpe1 /tmp/zpe0
+rocprofv3 --kernel-trace --stats -d /tmp/zpe1 -o kt -- python3 $R/bench.py --steps 2 --warmup 1 --poses 886 --hypo 1 --no-cpu-baseline --no-alt-mode > /dev/null 2>&1
+python3 $R/tools/rocpd_summary.py $(find /tmp/zpe1 -name '*_results.db' | head -1) > $R/gpurun_out/kernel_stats_${TAG}_cfg1.txt
+rocprofv3 --kernel-trace --stats -d /tmp/zpe0 -o kt -- python3 $R/bench.py --steps 4 --warmup 1 --poses 64 --hypo 1 --oil 100 --no-cpu-baseline --no-alt-mode > /dev/null 2>&1
+python3 $R/tools/rocpd_summary.py $(find /tmp/zpe0 -name '*_results.db' | head -1) > $R/gpurun_out/kernel_stats_${TAG}_cfg0.txt
+cd $R
+# the HIP-side ensembles of the three configs[2] captures (tests/test_ensemble_gpu.py asserts on shorter ones)
+python tools/ensemble_gpu.py --members 32 --out gpurun_out/ensemble_${TAG} > gpurun_out/ensemble_${TAG}.log 2>&1
+tail -3 gpurun_out/ensemble_${TAG}.log | cut -c1-400
 head -12 gpurun_out/kernel_stats_${TAG}.txt | cut -c1-170

@@ -565,7 +565,12 @@ constexpr int IPO_ROW_TB = 128;
 template <int KJ, int S>
 __device__ __forceinline__ void ipo_slot(const float (&K)[9], const float (&T0)[3], const IpoRot &o, const float (&x)[KJ], const float (&y)[KJ],
                                          const float (&z)[KJ], const float *cu, const float *cv, float inv_norm, float (&t)[10]) {
-    if constexpr (S < KJ) {
+#ifdef ZEDO_MUT_IPO_JOINT     // tools/mutation_check.py only: the last joint of a 17-joint key list is lost (both kernels)
+    constexpr bool live = S < KJ && S < 16;
+#else
+    constexpr bool live = S < KJ;
+#endif
+    if constexpr (live) {
         ipo_joint_terms(K, T0, o, x[S], y[S], z[S], cu[S * IPO_ROW_TB], cv[S * IPO_ROW_TB], inv_norm, t);
     } else {
 #pragma unroll
