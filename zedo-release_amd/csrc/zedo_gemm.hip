@@ -587,6 +587,13 @@ static LayerArgs rows_of(const LayerArgs &a, int row0, int rows) {
 template <int EPI>
 static hipError_t launch_small(const LayerArgs &a, hipStream_t st) {
     const int ncol = a.N / 128, cus = num_cus();
+    // up to one tile per CU: 64x64 tiles (four waves of 32x32, the same 512-MFMA chain per wave as a 32x128 tile and the same
+    // number of workgroups) stream 64 + 64 operand rows per K tile instead of 32 + 128: 16 LDS-DMA instructions instead of 20,
+    // each worth ~60 matrix-pipe cycles on the issuing SIMD - 886 rows: 19.9 -> 19.3 us per layer, 99.2 -> 96.8 ms per
+    // 1000-step pass (round 4; bit-identical).  ZEDO_SMALL_TILE32: the 32x128 shape of rounds 1-3 (A/B knob).
+    static const bool tile32 = getenv("ZEDO_SMALL_TILE32") != nullptr;
+    if (!tile32 && a.Mp % 64 == 0 && (a.Mp / 64) * (a.N / 64) <= cus)
+        return launch_cfg<64, 64, 2, 2, EPI, 4, 0, 32, SCHED_THIN & 1>(a, st);
     if (a.Mp % 32 == 0 && (a.Mp / 32) * ncol <= cus) return launch_cfg<32, 128, 1, 4, EPI, 4, 0, 32, SCHED_THIN & 1>(a, st);
     auto cost = [&](int bm, int slots_per_cu, double tile_us) {
         if (a.Mp % bm) return 1e30;
