@@ -20,7 +20,8 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 dev = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")
 seen = {}
-for (H, N) in ((50, 1015), (50, 886), (7, 1015), (3, 333)):
+for (H, N) in ((50, 1015), (50, 886), (7, 1015), (3, 333),
+               (1, 886), (1, 64), (2, 1000), (50, 127), (50, 180)):      # round 4: split post_dense / 64x64 tiles, mixed tile launches
     d = syn.make_poses(N, seed=1)
     rng = np.random.default_rng(11)
     x0 = (0.25 * rng.standard_normal((H * N, 17, 3))).astype(np.float32)
@@ -35,4 +36,14 @@ for (H, N) in ((50, 1015), (50, 886), (7, 1015), (3, 333)):
         digests.add(hashlib.sha256(x.cpu().numpy().tobytes() + T.cpu().numpy().tobytes()).hexdigest())
     print(f"rows {H * N}: {reps} runs x {S} steps -> {len(digests)} distinct result(s)")
     seen[H * N] = len(digests)
+    # the IPO fit (round 4: half-wave kernel below 17 408 rows x 17 joints, lane-per-row twin above): 500 iterations, run to run
+    cl = syn.make_clusters(H, seed=2)
+    x0c = dev((cl - cl[:, 0:1]).astype(np.float32))
+    uv, K = dev(d["db_2d"][:, :, :2]), dev(d["camera_param"])
+    digests = set()
+    for r in range(max(3, reps // 3)):
+        R, T = zh.ipo_fit(x0c, uv, K, list(range(17)), "z", 8.0, 0.2, 2.0, 500, N * 34, H * N)
+        digests.add(hashlib.sha256(R.cpu().numpy().tobytes() + T.cpu().numpy().tobytes()).hexdigest())
+    print(f"rows {H * N}: IPO x {max(3, reps // 3)} -> {len(digests)} distinct result(s)")
+    seen[("ipo", H * N)] = len(digests)
 sys.exit(0 if all(v == 1 for v in seen.values()) else 1)
