@@ -135,5 +135,20 @@ def test_drivers_under_torchrun_with_four_ranks_equal_the_one_rank_run(tmp_path)
         res = np.load(d / "results.npy")
         assert res.shape == (26, 3, 17, 3) and np.isfinite(res).all()
         shas[n] = hashlib.sha256(res.tobytes()).hexdigest()
+        # a sampler configuration OUTSIDE the fused pipeline (reverse-diffusion predictor; deterministic under the forced
+        # probability flow): the step-wise loop, the ranks sharing its hypothesis loop (5 hypotheses over 4 ranks: 2 + 2 + 1 + 0),
+        # the all-gather of uneven whole-hypothesis shards (gather_row_shards(lo=...))
+        cfg2 = d / "cfg_rd.py"
+        cfg2.write_text("import importlib.util\n"
+                        f"_s = importlib.util.spec_from_file_location('base_cfg', r'{cfg('h36m')}')\n"
+                        "_m = importlib.util.module_from_spec(_s); _s.loader.exec_module(_m)\n"
+                        "def get_config():\n"
+                        "    c = _m.get_config()\n"
+                        "    c.sampling.predictor = 'reverse_diffusion'\n"
+                        "    return c\n")
+        _driver(n, "run.inference", ["--config", str(cfg2), "--hypo", "5", "--synthetic", "9", "--oil_iterations", "4", "--out", str(d / "results_rd.npy")], d)
+        res2 = np.load(d / "results_rd.npy")
+        assert res2.shape == (9, 5, 17, 3) and np.isfinite(res2).all()
+        shas[(n, "rd")] = hashlib.sha256(res2.tobytes()).hexdigest()
     assert len(outs[1]) == 2 and outs[1] == outs[4], (outs[1], outs[4])          # the printed dataset means, digit for digit
-    assert shas[1] == shas[4]
+    assert shas[1] == shas[4] and shas[(1, "rd")] == shas[(4, "rd")]
