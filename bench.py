@@ -439,7 +439,7 @@ def main():
             if a.math == "f16x3":
                 roof = roofline_f16x3(hid, rows_launch)
             else:
-              roof = dict(bound="mfma", kernel="zedo::layer_pair_kernel<{GN_SILU|GN_SILU_RES}> (128x128 tiles on 16-deep K tiles, 3 workgroups per CU, + 32x128 / 64x128 remainder tiles in the same launch): "
+              roof = dict(bound="mfma", kernel="zedo::layer_pair_kernel<{GN_SILU|GN_SILU_RES}> (128x128 tiles on 16-deep K tiles, 3 workgroups per CU, + 64x64 / 64x128 remainder tiles in the same launch): "
                                              "one 1024x1024 dense layer + GroupNorm + SiLU [+ residual] over all rows",
                         achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,

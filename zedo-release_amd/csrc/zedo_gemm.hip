@@ -533,7 +533,10 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? (ZEDO_PAIR_RES_BK == 16 ? 6 : 
     } else {
         if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 2, EPI, 2, 0, ZEDO_PAIR_PLAIN_BK, ZEDO_PAIR_PLAIN_SCHED>(big, blockIdx.x, nbig);
         else if constexpr (ZEDO_PAIR_PLAIN_WGS == 4) layer_body<64, 128, 2, 2, EPI, 2, 0, 16, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
-        else layer_body<32, 128, 1, 4, EPI, 2, 0, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+        // remainder rows on 64x64 tiles (round 4; rounds 1-3: 32x128): the same number of tiles and the same 512-MFMA chain per wave,
+        // 64 + 64 instead of 32 + 128 operand rows per K tile = 16 instead of 20 LDS-DMA instructions (6 350 rows: 505.8 -> 496.3 ms
+        // per pass, 50 750 rows: 3107.8 -> 3099.9 ms, A/B/A/B on one box; bit-identical)
+        else layer_body<64, 64, 2, 2, EPI, 2, 0, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     }
     if (probe) { big.clk[0] = clock64() - c0; big.clk[1] = wall_clock64() - w0; }
 }
@@ -542,16 +545,16 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? (ZEDO_PAIR_RES_BK == 16 ? 6 : 
 
 template <int EPI, int W8>
 static hipError_t launch_pair(const LayerArgs &big, const LayerArgs &small, hipStream_t st) {
-    constexpr int SM = (W8 || ZEDO_PAIR_PLAIN_WGS == 4) ? 64 : 32;                      // remainder tile rows
+    constexpr int SM = 64, SN = (W8 || ZEDO_PAIR_PLAIN_WGS == 4) ? 128 : 64;             // remainder tile rows / columns
     constexpr int BKB = W8 ? ZEDO_PAIR_RES_BK : ZEDO_PAIR_PLAIN_BK;
     constexpr size_t lds_big = ((size_t)2 * (128 + 128) * BKB + 3 * 128) * sizeof(float);
-    constexpr size_t lds_small = ((!W8 && ZEDO_PAIR_PLAIN_WGS == 4) ? (size_t)64 * 128 + 3 * 128 : (size_t)2 * ((W8 ? 64 : 32) + 128) * 32 + 3 * 128) * sizeof(float);
+    constexpr size_t lds_small = ((!W8 && ZEDO_PAIR_PLAIN_WGS == 4) ? (size_t)64 * 128 + 3 * 128 : (size_t)2 * (SM + SN) * 32 + 3 * SN) * sizeof(float);
     constexpr size_t lds = lds_big > lds_small ? lds_big : lds_small;
     if (big.Mp % 128 || small.Mp % SM || big.N % 128 || big.K % 64) return hipErrorInvalidValue;
     auto kern = layer_pair_kernel<EPI, W8>;
     static std::atomic<bool> attr_done[MAX_DEVICES];      // per instantiation and per device
     if (hipError_t e = allow_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
-    const int nbig = (big.Mp / 128) * (big.N / 128), nsmall = (small.Mp / SM) * (small.N / 128);
+    const int nbig = (big.Mp / 128) * (big.N / 128), nsmall = (small.Mp / SM) * (small.N / SN);
     hipLaunchKernelGGL(kern, dim3(nbig + nsmall), dim3(W8 ? 512 : 256), lds, st, big, small, nbig);
     return hipGetLastError();
 }
@@ -640,7 +643,7 @@ static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
         if (mix_big > 0 && a.Mp > mix_big && (a.Mp - mix_big) % SMR == 0) {
             const double kd = a.K / 1024.0;
             const long small_tiles = (long)((a.Mp - mix_big) / SMR) * (a.N / 128);
-            const double est_mix = (mix_big / one_each) * 55.1 * kd + (double)((small_tiles + num_cus() - 1) / num_cus()) * (W8 ? 28.2 : 14.5) * kd + 6.0;
+            const double est_mix = (mix_big / one_each) * 55.1 * kd + (double)((small_tiles + num_cus() - 1) / num_cus()) * (W8 ? 28.2 : 13.9) * kd + 6.0;
             auto single = [&](int bm, int slots, double t) {
                 if (a.Mp % bm) return 1e30;
                 const long tiles = (long)(a.Mp / bm) * (a.N / 128);
