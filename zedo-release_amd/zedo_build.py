@@ -31,7 +31,12 @@ def ensure_library(allow_build=None):
         raise BuildError(f"{LIB_PATH} is missing and this process may not build it (ZEDO_NO_BUILD=1: the launcher builds "
                          "once, before it starts the ranks).  Build it with __graft_entry__.build() or `make -C "
                          f"{CSRC}`.  The ZeDO hot path has no CPU or PyTorch fallback.")
-    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+    try:
+        lock = open(os.path.join(CSRC, ".build.lock"), "w")
+    except OSError as e:          # a read-only tree cannot be built into either
+        raise BuildError(f"{LIB_PATH} is missing and {CSRC} is not writable ({e}).  The ZeDO hot path has no CPU or PyTorch "
+                         "fallback.") from e
+    with lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not os.path.exists(LIB_PATH):          # nobody built it while this process waited for the lock
