@@ -962,6 +962,15 @@ def gen_driver_pw3d_full_env():
                       perturb=run)
 
 
+def gen_driver_h36m_full_env():
+    """The reference's own fp32 reproducibility on BASELINE configs[1] (gen_driver_h36m_full: 886 poses, one hypothesis, H36M
+    settings, action-wise means): the same run on detections moved by -1/0/+1 ulp, stream ZEDO_ENV_RUN = 1, 2, ...  3 CPU-minutes
+    per member on one thread."""
+    run = int(os.environ["ZEDO_ENV_RUN"])
+    assert run > 0
+    _driver_full_size(f"driver_h36m_full_env{run}", 886, 1, 1000, 101, 17, [0, 1, 4], 3.0, 0.5, "uniform", "h36m", CACHE, perturb=run)
+
+
 def gen_driver_pw3d_full_tied():
     """configs[2] with a CONTRACTIVE prior (syn.make_weights(prior="tied")): does the spread of the end-to-end MPJPE between
     two fp32 implementations - the IPO's chaotic last iterate carried through an expansive loop - collapse when the denoiser
@@ -1108,9 +1117,9 @@ GENS = dict(model=gen_model, weights_alt=gen_weights_alt, pc_step=gen_pc_step, r
             driver_pw3d_full_b=gen_driver_pw3d_full_b, driver_pw3d_full_c=gen_driver_pw3d_full_c,
             driver_ipo_pins=gen_driver_ipo_pins, driver_pw3d_full_oil64=gen_driver_pw3d_full_oil64, driver_pw3d_full_b_oil64=gen_driver_pw3d_full_b_oil64,
             driver_pw3d_full_c_oil64=gen_driver_pw3d_full_c_oil64, driver_pw3d_full_env=gen_driver_pw3d_full_env,
-            driver_pw3d_ipoens=gen_driver_pw3d_ipoens, driver_pw3d_full_tied=gen_driver_pw3d_full_tied, driver_full_env=gen_driver_full_env)
+            driver_pw3d_ipoens=gen_driver_pw3d_ipoens, driver_pw3d_full_tied=gen_driver_pw3d_full_tied, driver_full_env=gen_driver_full_env, driver_h36m_full_env=gen_driver_h36m_full_env)
 SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64", "driver_pw3d_full_b", "driver_pw3d_full_c", "driver_ipo_pins", "driver_pw3d_full_oil64", "driver_pw3d_full_b_oil64",
-        "driver_pw3d_full_c_oil64", "driver_pw3d_full_env", "driver_pw3d_ipoens", "driver_pw3d_full_tied", "driver_full_env"}     # only with --only
+        "driver_pw3d_full_c_oil64", "driver_pw3d_full_env", "driver_pw3d_ipoens", "driver_pw3d_full_tied", "driver_full_env", "driver_h36m_full_env"}     # only with --only
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
