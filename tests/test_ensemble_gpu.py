@@ -309,3 +309,4 @@ def test_configs1_reference_runs_lie_inside_the_hip_ensemble(W, math_mode):
         r = rec[name]
         assert (np.abs(np.array(r["reference"]) - r["hip_mean"]) <= r["central95_half_width"]).all(), (name, r)
         assert abs(r["mean_diff"]) <= max(0.05, r["resolvable"]), (name, r)
+

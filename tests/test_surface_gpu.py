@@ -190,6 +190,10 @@ def test_fused_driver_full_length_matches_reference(weights0, golden):
     # between the extremes of its seven runs (the IPO's chaotic last iterate through an expansive loop).  No standard-error
     # clause: one number from fixtures.
     assert abs(p2 - float(d["pa_mpjpe"])) < 5e-5, (p2, float(d["pa_mpjpe"]))
+    gtc = (d["db_3d"] - d["db_3d"][:, 0:1]).astype(np.float64)
+    e_hip = np.linalg.norm(mine - gtc[:, None], axis=-1).mean(-1).min(1)
+    e_ref = np.linalg.norm(ref.astype(np.float64) - gtc[:, None], axis=-1).mean(-1).min(1)
+    assert abs(e_ref.mean() - float(d["mpjpe"])) < 1e-6
     env = golden("driver_full_env")
     ref_runs = np.concatenate([[float(d["mpjpe"])], env["mpjpe"]])
     envelope = float(ref_runs.max() - ref_runs.min())
@@ -198,6 +202,24 @@ def test_fused_driver_full_length_matches_reference(weights0, golden):
                             "reference_runs_mm": [float(v) * 1e3 for v in ref_runs]}) + "\n")
     assert abs(p1 - float(d["mpjpe"])) <= max(5e-5, envelope), (p1, float(d["mpjpe"]), envelope)
     assert np.abs(env["pa_mpjpe"] - float(d["pa_mpjpe"])).max() < 5e-5          # the reference against itself meets the bar in PA-MPJPE
+    # WHERE the difference of the means sits (round 4): in 160 best-of-3 values it is two or three single fits that land in
+    # another basin - with round 4's kernels pose 147 (hypothesis 1: 1670.5 mm here, 1590.3 mm in the reference and in the numpy
+    # oracle) and pose 2 (1376.6 here AND in the oracle, 1345.5 in the reference): 80 + 31 mm of the 107 mm that make the 0.67 mm.
+    # A one-ulp change of the detections does not move such a fit out of its basin in a given implementation (32 HIP members:
+    # 1311.69 +- 0.05 mm; six oracle members: 1311.18 +- 0.04; the reference: six of seven runs 1310.98 ... 1311.24, one 1311.74),
+    # another summation order does (round 3's: 1311.79, a plain xor butterfly: 1311.12) - so this small problem has no meaningful
+    # ensemble and is held per pose instead: at most 2 % of the poses more than 20 mm apart, and the mean over the others
+    # within the north-star's 0.05 mm.
+    dpose = (e_hip - e_ref) * 1e3                                              # mm, per pose (best of 3)
+    order = np.argsort(-np.abs(dpose))
+    k = int(np.ceil(0.02 * len(dpose)))                                        # 4 of 160
+    rest = dpose[order[k:]]
+    with open("gpurun_out/parity_report.jsonl", "a") as f:
+        f.write(json.dumps({"test": "driver_full_per_pose", "largest_mm": [[int(i), float(dpose[i])] for i in order[:5]],
+                            "poses_beyond_20mm": int((np.abs(dpose) > 20).sum()), "mean_without_top_2pct_mm": float(rest.mean()),
+                            "median_abs_mm": float(np.median(np.abs(dpose)))}) + "\n")
+    assert int((np.abs(dpose) > 20).sum()) <= k, dpose[order[:6]]
+    assert abs(rest.mean()) <= 0.05, (rest.mean(), dpose[order[:6]])
 
 
 def test_reference_loop_through_the_per_step_surface(model, weights0):
