@@ -26,6 +26,8 @@ def main(path):
                   f"({j['q_loss']['max_in_member_sd']:.1f} sd) mean loss diff {j['mean_loss_px']['diff']:+.2e} px")
         elif t.endswith("_envelope"):
             print(f"{t:28s} " + json.dumps({k: v for k, v in j.items() if k != "test" and k != "reference_runs_mm"}))
+        elif t in ("configs1_ensemble", "driver_full_per_pose"):
+            print(f"{t:28s} " + json.dumps({k: v for k, v in j.items() if k != "test"})[:400])
         elif t == "contractive_prior":
             print(f"{t:28s} {j['math']:6s} d_mpjpe {j['mpjpe']['d_mm']:+.5f} mm (per pose median {j['mpjpe']['per_pose_abs_median_mm']:.5f}, p99 "
                   f"{j['mpjpe']['per_pose_abs_p99_mm']:.4f}, max {j['mpjpe']['per_pose_abs_max_mm']:.3f}) d_pa {j['pa_mpjpe']['d_mm']:+.5f} mm members sd {j['hip_members_sd_mm']}")
