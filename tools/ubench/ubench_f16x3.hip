@@ -217,6 +217,173 @@ __global__ __launch_bounds__(WM *WN * 64, WPE) void hf_kernel(Args a) {
     if (probe_) { a.clk[0] = clock64() - c0_; a.clk[1] = wall_clock64() - w0_; }
 }
 
+#ifndef FOR_TILES
+#define FOR_TILES(stmt) _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j) { stmt; }
+#endif
+
+// ---- round 5: LOADER WAVES.  tools/ubench/ubench_vmem_issue.hip shows that an LDS-DMA instruction stalls only the wave that
+// issues it (~70 cycles) and costs the MFMA stream of ANOTHER wave on the same SIMD nothing.  Here the tile's WM x WN MFMA waves
+// (one per SIMD) never touch vector memory inside the k loop: NL extra waves of the same workgroup issue every DMA, paced by the
+// same one-barrier-per-stage ring protocol (a stage = KPS 16-k blocks).
+//   loader, stage st:  vmcnt -> stage st+1 landed | barrier st | DMA stage st+NBUF -> slot st % NBUF (every MFMA wave has read stage st)
+//   MFMA wave:         lgkmcnt(0) (fragments read so far are in registers) | barrier st | per block: read the next block, MFMA this block
+// FLAGS: 1 no in-loop DMA, 2 fragment reads interleaved between the MFMAs (one wave per SIMD has nobody to fill its read phase), 4 no epilogue
+template <int BM, int BN, int WM, int WN, int NBUF, int NL, int FLAGS = 0, int KPS = 1>
+__global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) / 4) void hf_lw_kernel(Args a) {
+    long long c0_ = 0, w0_ = 0;
+    const bool probe_ = a.clk && blockIdx.x == 0 && threadIdx.x == 0;
+    if (probe_) { c0_ = clock64(); w0_ = wall_clock64(); }
+    constexpr int NW = WM * WN, TM = BM / WM, TN = BN / WN, TJ = TM / 32, TI = TN / 32;
+    constexpr int RB = 64 * KPS, CPR = RB / 16;
+    constexpr int IPB = (BN + BM) * CPR / 64;                 // DMA instructions per stage (W rows first, then X rows)
+    static_assert(IPB % NL == 0, "loaders");
+    constexpr int IPL = IPB / NL;                             // per loader wave
+    static_assert((NBUF - 1) * IPL <= 63 && (NBUF * KPS) % 2 == 0, "vmcnt / fragment set parity");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SLOT = (BN + BM) * RB;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int ncol = a.N / BN;
+    const int m0 = (lid / ncol) * BM, n0 = (lid % ncol) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t rstride = (size_t)(a.K / 16) * 64;
+    const int NST = a.K / (16 * KPS);
+    auto swz = [](int row) { return CPR == 4 ? ((row >> 2) & 3) : (row & 7); };
+    if (wid >= NW) {
+        // ---------------- loader wave ----------------
+        const int l = wid - NW;
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+        unsigned off[IPL];
+        const char *base[IPL];
+#pragma unroll
+        for (int i = 0; i < IPL; ++i) {
+            const int p = l * IPL + i;
+            const int g = p * 64 + lane, r_ = g / CPR, c_ = (g % CPR) ^ swz(r_);
+            const bool isw = (p * 64 / CPR) < BN;
+            const int rr = isw ? r_ : r_ - BN;
+            off[i] = (unsigned)(rr * rstride + c_ * 16);
+            base[i] = isw ? reinterpret_cast<const char *>(a.W2) + (size_t)n0 * rstride : reinterpret_cast<const char *>(a.X2) + (size_t)m0 * rstride;
+        }
+        auto dma = [&](int st, int slot) {
+#pragma unroll
+            for (int i = 0; i < IPL; ++i) dma16(base[i] + (size_t)st * RB, off[i], lds0 + slot * SLOT + (l * IPL + i) * 1024);
+        };
+#pragma unroll
+        for (int t = 0; t < NBUF; ++t) dma(min(t, NST - 1), t);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * IPL) : "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int st0 = 0; st0 < NST; st0 += NBUF) {
+#pragma unroll
+            for (int slot = 0; slot < NBUF; ++slot) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPL) : "memory");
+                __builtin_amdgcn_s_barrier();
+                if (!(FLAGS & 1)) dma(min(st0 + slot + NBUF, NST - 1), slot);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    // ---------------- MFMA wave ----------------
+    const int wm = wid / WN, wn = wid % WN, li = lane & 31, kh = lane >> 5;
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    f16x8 fa[2][TI][2], fb[2][TJ][2];
+    const int fs = swz(li);
+    const char *Abase = smem + (wn * TN + li) * RB, *Bbase = smem + BN * RB + (wm * TM + li) * RB;
+    // read number r of a block (TI * 2 A pieces, then TJ * 2 B pieces) into fragment set `set`
+    auto read1 = [&](int set, int slot, int kb, int r) {
+        if (r < TI * 2) { const int i = r >> 1, pl = r & 1; fa[set][i][pl] = *reinterpret_cast<const f16x8 *>(Abase + slot * SLOT + i * 32 * RB + (((kb * 4 + pl * 2 + kh) ^ fs) * 16)); }
+        else { const int j = (r - TI * 2) >> 1, pl = r & 1; fb[set][j][pl] = *reinterpret_cast<const f16x8 *>(Bbase + slot * SLOT + j * 32 * RB + (((kb * 4 + pl * 2 + kh) ^ fs) * 16)); }
+    };
+    constexpr int NR = (TI + TJ) * 2, NM = 3 * TI * TJ;
+    auto mma1 = [&](int set, int m) {                          // MFMA number m of a block: product-major (lh, hl, hh), tiles inside
+        const int prod = m / (TI * TJ), t = m % (TI * TJ), i = t / TJ, j = t % TJ;
+        const int ap = prod == 0 ? 1 : 0, bp = prod == 1 ? 1 : 0;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][ap], fb[set][j][bp], acc[i][j], 0, 0, 0);
+    };
+    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_barrier();           // stage 0 landed
+#pragma unroll
+    for (int r_ = 0; r_ < NR; ++r_) read1(0, 0, 0, r_);
+    for (int st0 = 0; st0 < NST; st0 += NBUF) {
+#pragma unroll
+        for (int slot = 0; slot < NBUF; ++slot) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int kb = 0; kb < KPS; ++kb) {
+                const int set = (slot * KPS + kb) & 1;
+                const int nslot = kb + 1 < KPS ? slot : (slot + 1) % NBUF, nkb = kb + 1 < KPS ? kb + 1 : 0;
+                if constexpr ((FLAGS & 2) != 0) {
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        mma1(set, m);
+                        if (m < NR) read1(set ^ 1, nslot, nkb, m);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int r_ = 0; r_ < NR; ++r_) read1(set ^ 1, nslot, nkb, r_);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) mma1(set, m);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr ((FLAGS & 4) != 0) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s_ += acc[i][j][e];
+        if (s_ == 1234.5f) a.out[0] = s_;
+    } else {
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int cbase = n0 + wn * TN + i * 32 + 4 * kh;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int m = m0 + wm * TM + j * 32 + li;
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaf(acc[i][j][4 * g + e], a.unscale, a.bias[cbase + 8 * g + e]);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += v[e];
+            s += __shfl_xor(s, 32);
+            const float mean = s * (1.f / 32.f);
+            float qs = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { v[e] -= mean; qs += v[e] * v[e]; }
+            qs += __shfl_xor(qs, 32);
+            const float rstd = __builtin_amdgcn_rsqf(qs * (1.f / 32.f) + 1e-5f);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = silu_fast(v[4 * g + e] * (rstd * a.gamma[cbase + 8 * g + e]) + a.beta[cbase + 8 * g + e]);
+                *reinterpret_cast<f32x4 *>(a.out + (size_t)m * a.N + cbase + 8 * g) = o;
+            }
+        }
+    }
+    }
+    if (probe_) { a.clk[0] = clock64() - c0_; a.clk[1] = wall_clock64() - w0_; }
+}
+
 static inline uint16_t f16_rn(float f) { __half h = __float2half_rn(f); uint16_t u; memcpy(&u, &h, 2); return u; }
 static inline float f16_to_f(uint16_t u) { __half h; memcpy(&h, &u, 2); return __half2float(h); }
 static void split2(const std::vector<float> &src, int rows, int K, float scale, std::vector<uint16_t> &dst, double *resid) {
@@ -264,6 +431,40 @@ int run(const char *name, Args a, const std::vector<int> &rows, const std::vecto
     long long ck[2] = {0, 0}; CK(hipMemcpy(ck, a.clk, 16, hipMemcpyDeviceToHost));
     const double ghz = ck[1] > 0 ? (double)ck[0] / ((double)ck[1] / 100e6) / 1e9 : 0.0;
     // matrix-pipe time of this launch at the clock it ran at: 3 MFMAs x 32 cycles per 32x32x16 block, 1024 SIMDs
+    const double mfma_us = 3.0 * 32.0 * ((double)a.M / 32) * (a.N / 32) * (a.K / 16) / 1024.0 / (ghz * 1e3);
+    printf("%-46s: %7.1f us  %6.1f TF(fp32-eq)  max|y-ref64| %.2e rms %.2e  bad %d  [lds %zu KB]  clock %.3f GHz  MFMA-only %.0f us (%.0f%%)\n", name, ms * 1e3,
+           2.0 * a.M * a.N * a.K / ms / 1e9, maxd, sqrt(sq / cnt), nbad, lds / 1024, ghz, mfma_us, 100.0 * mfma_us / (ms * 1e3));
+    return 0;
+}
+
+
+template <int BM, int BN, int WM, int WN, int NBUF, int NL, int FLAGS = 0, int KPS = 1>
+int run_lw(const char *name, Args a, const std::vector<int> &rows, const std::vector<double> &cref) {
+    constexpr size_t lds = (size_t)NBUF * (BM + BN) * 64 * KPS;
+    constexpr int NT = (WM * WN + NL) * 64;
+    auto kern = hf_lw_kernel<BM, BN, WM, WN, NBUF, NL, FLAGS, KPS>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nwg = (a.M / BM) * (a.N / BN);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipMemset(a.out, 0xff, (size_t)a.M * a.N * 4));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, 0, a);
+    CK(hipDeviceSynchronize());
+    std::vector<float> y((size_t)a.M * a.N);
+    CK(hipMemcpy(y.data(), a.out, y.size() * 4, hipMemcpyDeviceToHost));
+    double maxd = 0, sq = 0; int nbad = 0; size_t cnt = 0;
+    for (size_t ri = 0; ri < rows.size(); ++ri) {
+        double d = 0;
+        for (int n = 0; n < a.N; ++n) { double dd = fabs((double)y[(size_t)rows[ri] * a.N + n] - cref[ri * a.N + n]); sq += dd * dd; ++cnt; if (!(dd <= d)) d = dd; }
+        if (!(d <= 1e-4)) ++nbad;
+        if (!(d <= maxd)) maxd = d;
+    }
+    for (int r = 0; r < 200; ++r) hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, 0, a);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 100; ++r) hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, 0, a);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 100;
+    long long ck[2] = {0, 0}; CK(hipMemcpy(ck, a.clk, 16, hipMemcpyDeviceToHost));
+    const double ghz = ck[1] > 0 ? (double)ck[0] / ((double)ck[1] / 100e6) / 1e9 : 0.0;
     const double mfma_us = 3.0 * 32.0 * ((double)a.M / 32) * (a.N / 32) * (a.K / 16) / 1024.0 / (ghz * 1e3);
     printf("%-46s: %7.1f us  %6.1f TF(fp32-eq)  max|y-ref64| %.2e rms %.2e  bad %d  [lds %zu KB]  clock %.3f GHz  MFMA-only %.0f us (%.0f%%)\n", name, ms * 1e3,
            2.0 * a.M * a.N * a.K / ms / 1e9, maxd, sqrt(sq / cnt), nbad, lds / 1024, ghz, mfma_us, 100.0 * mfma_us / (ms * 1e3));
@@ -355,5 +556,16 @@ int main(int argc, char **argv) {
     RUN("128x256 4w(64x128) ring4 k16 lb2", 128, 256, 2, 2, 4, 0, 2, 1)
     RUN("128x256 4w(64x128) k16 lb2 no DMA", 128, 256, 2, 2, 2, 1, 2, 1)
     RUN("256x256 8w(64x128) ring2 k16 lb2 again", 256, 256, 4, 2, 2, 0, 2, 1)
+#define RUNLW(NAME, ...) { if (only < 0 || only == v) run_lw<__VA_ARGS__>(NAME, a, rows, cref); ++v; }
+    //      BM   BN  WM WN NBUF NL
+    RUNLW("LW 128x256 4+4 ring4", 128, 256, 2, 2, 4, 4)
+    RUNLW("LW 128x256 4+4 ring4 no DMA", 128, 256, 2, 2, 4, 4, 1)
+    RUNLW("LW 128x256 4+4 ring4 interleaved reads", 128, 256, 2, 2, 4, 4, 2)
+    RUNLW("LW 128x256 4+4 ring4 interleaved, no epilogue", 128, 256, 2, 2, 4, 4, 6)
+    RUNLW("LW 128x256 4+4 ring4 interleaved, no epilogue, no DMA", 128, 256, 2, 2, 4, 4, 7)
+    RUNLW("LW 128x256 4+4 ring2 k32 interleaved", 128, 256, 2, 2, 2, 4, 2, 2)
+    RUNLW("LW 128x256 4+4 ring2 k32 interleaved, no epilogue", 128, 256, 2, 2, 2, 4, 6, 2)
+    RUNLW("LW 128x256 4+4 ring2 k32 interleaved, no epi, no DMA", 128, 256, 2, 2, 2, 4, 7, 2)
+    RUNLW("LW 128x256 4+2 ring2 k32 interleaved, no epilogue", 128, 256, 2, 2, 2, 2, 6, 2)
     return 0;
 }
