@@ -259,12 +259,13 @@ def supervise(procs, poll_s=0.2):
     return rc
 
 
-def launch_ranks(n, argv, dry=False, cmd=None):
+def launch_ranks(n, argv, dry=False, cmd=None, build=True):
     """`python bench.py --gpus N` without a torchrun environment: start N fresh processes, one per GPU.  The parent makes
     no HIP call of its own (it only counts devices; the ranks are fresh child processes either way, never an exec of
     this one), builds / verifies libzedo_hip.so ONCE before it starts them and exports ZEDO_NO_BUILD=1, so that the
     ranks fail loudly instead of racing N `make`s; a failing rank ends the others and the parent exits with its code.
-    ZEDO_SHARE_DEVICE=1 + ZEDO_DIST_BACKEND=gloo: all N ranks on device 0 (rehearsal on a one-GPU box)."""
+    ZEDO_SHARE_DEVICE=1 + ZEDO_DIST_BACKEND=gloo: all N ranks on device 0 (rehearsal on a one-GPU box).
+    build=False (tests of the launcher logic with stand-in rank commands): the parent neither builds nor looks for the library."""
     import subprocess
     import zedo_build
     share = os.environ.get("ZEDO_SHARE_DEVICE") == "1"
@@ -286,12 +287,94 @@ def launch_ranks(n, argv, dry=False, cmd=None):
     if share and os.environ.get("ZEDO_DIST_BACKEND", "nccl").lower() != "gloo":
         print("bench.py: ZEDO_SHARE_DEVICE=1 needs ZEDO_DIST_BACKEND=gloo (RCCL refuses two ranks on one device)", file=sys.stderr)
         return 2
-    try:
-        zedo_build.ensure_library(allow_build=True)       # once, here - never in the ranks
-    except ImportError as e:
-        print(f"bench.py: {e}", file=sys.stderr)
-        return 3
+    if build:
+        try:
+            # once, here - never in the ranks; a parent that was itself told not to build (ZEDO_NO_BUILD=1) only verifies
+            zedo_build.ensure_library(allow_build=os.environ.get("ZEDO_NO_BUILD") != "1")
+        except ImportError as e:
+            print(f"bench.py: {e}", file=sys.stderr)
+            return 3
     return supervise([subprocess.Popen(cmd, env=e) for e in envs])
+
+SELFCHECK = dict(poses=64, hypo=5, oil=20)     # the fixed small problem of multi_rank_selfcheck
+
+
+def multi_rank_selfcheck(zp, dist, weights, wl, dev, rank, world):
+    """Before anything is timed: does the N-rank result equal the one-rank result, bit for bit, on THIS transport?
+    The reference is one GPU running its hypotheses one after the other (run/opt_main.py:166, 224-228); sharding rows over
+    ranks is this repository's addition, and `bench.py --gpus N` under the driver is the only place a process group with more
+    than one RCCL member ever runs - so the run checks itself.  A fixed small problem (64 poses x 5 hypotheses x 20 steps, the
+    workload's own settings, selection or gather) is processed (a) sharded over the ranks of the live process group, through
+    the very exchange step that is about to be timed, and (b) unsharded on rank 0 with no collective at all; both digests
+    travel in the JSON line and a mismatch makes EVERY rank exit with code 4 before the timed region.
+    ZEDO_BENCH_CORRUPT_RANK=k (test hook): rank k adds 1e-3 m to its shard before the exchange."""
+    import hashlib
+    from zedo_hip.pipeline import Pipeline, ZeDOConfig, gather_row_shards, reduce_min_over_ranks, shard_rows
+    from lib.dataset import synthetic as syn
+    N, H, S = SELFCHECK["poses"], SELFCHECK["hypo"], SELFCHECK["oil"]
+    h36m = wl["settings"] == "h36m"
+    d = syn.make_poses(N, seed=77, dtype3d=np.float64 if (h36m and wl["select"] == "h36m") else np.float32)
+    cfg = (ZeDOConfig.h36m if h36m else ZeDOConfig.pw3d)(OIL_iterations=S)
+    pipe = Pipeline(weights, cfg, dev).load(syn.make_clusters(H, seed=77), d["db_2d"], d["camera_param"])
+    if wl["select"] == "h36m":
+        mm = d["db_3d"] * 1000.0
+        gt = (mm - mm[:, 0:1]) / 1000.0
+    else:
+        gt = (d["db_3d"] - d["db_3d"][:, 0:1]).astype(np.float64)
+    gt_dev = torch.tensor(gt, dtype=torch.float64, device=dev)
+    corrupt = os.environ.get("ZEDO_BENCH_CORRUPT_RANK")
+
+    def digest(x, lo, exchange):
+        h = hashlib.sha256()
+        if wl["select"] == "gather":
+            res = gather_row_shards(x, H * N) if exchange else x
+            h.update(res.cpu().numpy().tobytes())
+        else:
+            sel = pipe.select(x, gt_dev, row_offset=lo)
+            for k in ("p1", "p2"):
+                best, idx = reduce_min_over_ranks(*sel[k]) if exchange else sel[k]
+                h.update(best.cpu().numpy().tobytes())
+                h.update(idx.cpu().numpy().astype(np.int32).tobytes())
+        return h.hexdigest()[:16]
+
+    lo, rows = shard_rows(H * N, rank, world)
+    x, _ = pipe.run(row_offset=lo, rows=rows)
+    if corrupt is not None and rank == int(corrupt):
+        x = x + 1e-3
+    sharded = digest(x, lo, True)
+    whole = None
+    bad = 0
+    if rank == 0:
+        xw, _ = pipe.run()
+        whole = digest(xw, 0, False)
+        bad = int(whole != sharded)
+    flag = torch.tensor([bad], dtype=torch.int64, device=dev)
+    zp.all_reduce(flag, dist.ReduceOp.MAX)
+    ok = int(flag.item()) == 0
+    return dict(ok=ok, sha=sharded, sha_unsharded=whole, backend=dist.get_backend(), ranks=world,
+                problem=f"{N} poses x {H} hypotheses x {S} steps, {wl['settings']} settings, "
+                        f"{'all-gather' if wl['select'] == 'gather' else 'P1/P2 MIN exchange'}; rows sharded {world}-way vs unsharded on rank 0")
+
+
+def strong_projection(rows_per_rank, math):
+    """What ONE GPU measured for a shard of this many rows of workload 2 (profiles/strong_shards_r04.jsonl: bench.py --poses ...
+    on one MI355X) -> pass time in ms, or None when no shard within 2 % of this size was measured."""
+    tp = os.path.join(ROOT, "profiles", "strong_shards_r04.jsonl")
+    if not os.path.exists(tp):
+        return None
+    best = None
+    for l in open(tp):
+        try:
+            j = json.loads(l)
+        except ValueError:
+            continue
+        r = j.get("config", {}).get("rows_per_gpu")
+        if not r or abs(r - rows_per_rank) > 0.02 * rows_per_rank:
+            continue
+        ms = j["ms_per_step"] if j.get("math") == math else (j.get("alt_mode") or {}).get("ms_per_step")
+        if ms and (best is None or abs(r - rows_per_rank) < abs(best[0] - rows_per_rank)):
+            best = (r, float(ms))
+    return best
 
 
 def main():
@@ -362,6 +445,15 @@ def main():
 
     fail_rank = os.environ.get("ZEDO_BENCH_FAIL_RANK")      # test hook: that rank dies before the exchange step
 
+    selfcheck = None
+    if use_dist:     # every run that has a process group checks N ranks == 1 rank before it times anything
+        selfcheck = multi_rank_selfcheck(zp, dist, weights, wl, dev, rank, world)
+        if not selfcheck["ok"]:
+            if rank == 0:
+                print(f"bench.py: multi_rank_selfcheck FAILED - {world} ranks over {selfcheck['backend']} give {selfcheck['sha']}, "
+                      f"one rank gives {selfcheck['sha_unsharded']} ({selfcheck['problem']})", file=sys.stderr, flush=True)
+            sys.exit(4)
+
     def one_pass():
         x, T = pipe.run(row_offset=lo, rows=rows)
         if fail_rank is not None and rank == int(fail_rank):
@@ -396,19 +488,25 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         prof = zh.profile_stop()
+        per_rank = [dt]
         if use_dist:
+            # every rank's own time of the K passes (between the two fences): value uses the MAX, the JSON shows all of them
+            mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+            allt = torch.empty((world,), dtype=torch.float64, device=dev)
+            zp.all_gather_into_tensor(allt, mine)
+            per_rank = [float(v) for v in allt.cpu().tolist()]
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             zp.all_reduce(tt, dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt, prof, x, out
+        return dt, prof, x, out, per_rank
 
-    dt, prof, x, out = timed_run()
+    dt, prof, x, out, per_rank = timed_run()
     # the other arithmetic mode of the hidden layers on the same problem (reported as alt_mode, never as `value`)
     alt = None
     if not a.no_alt_mode and wl["select"] != "gather":
         alt_math = "f16x3" if a.math == "f32" else "f32"
         pipe.weights.set_math(alt_math)
-        dt2, prof2, _, out2 = timed_run()
+        dt2, prof2, _, out2, _ = timed_run()
         pipe.weights.set_math(a.math)
         alt = dict(math=alt_math, dt=dt2, prof=prof2, out=out2)
 
@@ -507,7 +605,20 @@ def main():
             "event_bracket_ms": round(prof["hidden_dense"].get("bracket_ms") or 0.0, 5),
             "sum_kernel_ms_per_oil_step": round(sum(v["launches"] * v["avg_ms"] for v in prof.values() if v["avg_ms"]) / (a.steps * S), 5),
             "wall_ms_per_oil_step": round(dt * 1e3 / (a.steps * S), 5),
+            # N ranks == 1 rank, bit for bit, on the live transport, checked before the timed region (None without a process group)
+            "multi_rank_selfcheck": selfcheck,
+            # each rank's own seconds per pass between the fences (value / ms_per_step use the maximum)
+            "rank_pass_s": {"min": round(min(per_rank) / a.steps, 5), "max": round(max(per_rank) / a.steps, 5),
+                            "argmin": int(np.argmin(per_rank)), "argmax": int(np.argmax(per_rank)),
+                            "all": [round(v / a.steps, 5) for v in per_rank]},
         }
+        if scaling == "strong" and a.workload == 2 and S == S_OIL and H == N_HYPO:
+            # strong scaling of configs[2]: what one GPU measured for a shard of this size (no communication) against this run
+            proj = strong_projection(rows, a.math)
+            line["efficiency_vs_projection"] = (dict(projected_ms_per_step=proj[1], projected_rows_per_rank=proj[0],
+                                                     measured_ms_per_step=round(ms_per_step, 2), efficiency=round(proj[1] / ms_per_step, 4),
+                                                     source="profiles/strong_shards_r04.jsonl (one MI355X running the shard of one rank)")
+                                                if proj else None)
         if alt is not None:
             h2 = alt["prof"]["hidden_dense"]
             pps2 = N_total * a.steps / alt["dt"]

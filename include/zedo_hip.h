@@ -14,10 +14,14 @@
  *    it and nothing synchronises unless stated;
  *  - functions write only caller-allocated outputs and the caller-provided workspace; the only
  *    library-owned device memory lives inside zedo_weights_t / zedo_schedule_t handles;
- *  - calls on distinct streams may run concurrently (one process per GPU is the intended use; a second device
- *    in the same process works: launch attributes are cached per device).  Process-wide state exists only
- *    outside the data path: the zedo_profile_* diagnostic (one session at a time; thread safe) and the
- *    ZEDO_CHUNK_ROWS environment value, read once;
+ *  - calls on distinct streams may run concurrently, from one host thread or several, provided each call has its own
+ *    workspace and outputs (one process per GPU is the intended use; a second device in the same process works: launch
+ *    attributes are cached per device; a call runs on the device that is current when it is made, which must be the
+ *    device of its pointers and of `stream`).  Handles are read-only to the row-batched entry points and may be shared
+ *    by concurrent calls; zedo_weights_set_math is the exception (switch modes between runs, not during them).
+ *    Process-wide state exists only outside the data path: the zedo_profile_* diagnostic (one session at a time; thread
+ *    safe; samples launches of every stream) and the ZEDO_CHUNK_ROWS environment value, read once.
+ *    tests/test_reentrancy_gpu.py runs two host threads x two streams through this contract;
  *  - rows are hypothesis-major: global row g = h*N + n (h = hypothesis, n = pose) - the order in
  *    which the reference's hypothesis loop produces them (run/opt_main.py:166-222).  A call may
  *    hold any contiguous shard of the global rows: local row b is global row row_offset + b, so
@@ -161,8 +165,9 @@ int zedo_oil_run(const zedo_weights_t *w, const zedo_schedule_t *s, float *d_x, 
  * when rows are sharded).  d_x0 [H,J,3] (centred cluster poses), d_uv [N,J,2], d_K [N,3,3],
  * h_keylist[k] joint indices, axes_mask bit0=x bit1=y bit2=z.
  * Outputs: d_R [B,3,3], d_T [B,3] = T0*clamp(scale), optional d_q [B,4], d_scale [B] (may be NULL).
- * h_keylist is consumed before the call returns (it travels as a kernel argument); nothing synchronises, except the
- * first fit of a process on a device (a blocking 16 KB copy of Adam's bias-correction terms to constant memory).
+ * h_keylist is consumed before the call returns (it travels as a kernel argument); nothing synchronises and nothing is
+ * copied (Adam's bias-correction terms are constants of the code object): every call, the first one included, is a plain
+ * kernel launch on `stream` - legal under stream capture and safe beside fits on other streams or host threads.
  * The ten gradient sums over the key joints are formed in ONE fixed pairing order by both kernels behind this entry
  * point (one row per half-wave for small batches, one lane per row for large ones): a row's result does not depend on B,
  * row_offset, the shard it is in or the kernel that ran it.

@@ -54,7 +54,7 @@ def test_launcher_propagates_a_failing_rank():
         real = bench.torch.cuda.device_count
         bench.torch.cuda.device_count = lambda: 1
         t0 = time.time()
-        rc = bench.launch_ranks(2, [], cmd=[sys.executable, "-c", code])
+        rc = bench.launch_ranks(2, [], cmd=[sys.executable, "-c", code], build=False)   # launcher logic only: no hipcc, no tree edits
         dt = time.time() - t0
     finally:
         bench.torch.cuda.device_count = real
@@ -100,6 +100,19 @@ def test_missing_library_is_built_once_under_a_lock_or_refused(tmp_path):
     outs = [p.communicate(timeout=120)[0].strip() for p in procs]
     assert all(p.returncode == 0 for p in procs) and all(o.endswith("libzedo_hip.so") for o in outs), outs
     assert (pkg / "csrc" / "builds.log").read_text().count("x") == 1
+
+
+def test_strong_scaling_projection_reads_the_one_gpu_shard_measurements():
+    """bench.py --scaling strong reports efficiency_vs_projection against what ONE GPU measured for a rank's shard
+    (profiles/strong_shards_r04.jsonl); the self-check problem is fixed and small."""
+    sys.path.insert(0, ROOT)
+    import bench
+    r8, ms8 = bench.strong_projection(6344, "f32")           # configs[2] over 8 ranks: 6 344 rows on rank 0, measured at 6 350
+    assert r8 == 6350 and 400 < ms8 < 600
+    assert bench.strong_projection(6344, "f16x3")[1] < ms8       # the alt-mode time of the same record
+    assert bench.strong_projection(12688, "f32")[0] == 12700 and bench.strong_projection(25375, "f32")[0] == 25400
+    assert bench.strong_projection(9000, "f32") is None          # nothing measured within 2 %
+    assert bench.SELFCHECK == dict(poses=64, hypo=5, oil=20)
 
 
 def test_workload_table_matches_the_baseline_configs():
@@ -150,6 +163,11 @@ def test_valid_ind_mask_is_one_scatter_and_scales_to_the_full_test_set():
     for lo, cnt in ((0, H * N), (5, 40), (H * N - 9, 9), (17, 1)):
         got = valid_rows_mask(vi, N, lo, cnt, torch.device("cpu")).numpy()
         assert np.array_equal(got, flat[lo:lo + cnt]), (lo, cnt)
+        # the reference only ever evaluates `valid_ind[idx]`: a mapping {pose: hypotheses}, sets and generators-per-pose are as valid as a list
+        as_dict = {n: set(vi[n]) for n in range(N)}
+        assert np.array_equal(valid_rows_mask(as_dict, N, lo, cnt, torch.device("cpu")).numpy(), flat[lo:lo + cnt])
+        as_arrays = np.array([np.asarray(v, dtype=np.int64) for v in vi], dtype=object)
+        assert np.array_equal(valid_rows_mask(as_arrays, N, lo, cnt, torch.device("cpu")).numpy(), flat[lo:lo + cnt])
     N, H = 567040, 50
     vi = [(n % H, (n * 7) % H, (n * 13) % H) for n in range(N)]
     t0 = time.time()

@@ -34,7 +34,7 @@ BENCH = os.path.join(ROOT, "bench.py")
 def _env(share):
     e = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ZEDO_FORCE_DIST", "ZEDO_BENCH_FORCE_DIST",
-              "ZEDO_NO_BUILD", "ZEDO_SHARE_DEVICE", "ZEDO_DIST_BACKEND", "ZEDO_BENCH_FAIL_RANK"):
+              "ZEDO_NO_BUILD", "ZEDO_SHARE_DEVICE", "ZEDO_DIST_BACKEND", "ZEDO_BENCH_FAIL_RANK", "ZEDO_BENCH_CORRUPT_RANK"):
         e.pop(k, None)
     e["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     if share:
@@ -80,6 +80,12 @@ def test_eight_ranks_on_one_gpu_equal_the_one_rank_run(case):
     if key == "selection_sha16":
         assert a["mpjpe_best_of_H_m"] == b["mpjpe_best_of_H_m"] and a["pa_mpjpe_best_of_H_m"] == b["pa_mpjpe_best_of_H_m"]
     assert a["value"] > 0 and a["ms_per_step"] > 0 and a["scaling"] in ("weak", "strong")
+    # the run checked itself before it timed anything: 8 ranks == 1 rank on the live transport, every rank's own pass time reported
+    sc = a["multi_rank_selfcheck"]
+    assert sc["ok"] is True and sc["ranks"] == 8 and sc["backend"] == "gloo" and sc["sha"] == sc["sha_unsharded"] and len(sc["sha"]) == 16
+    assert b["multi_rank_selfcheck"] is None
+    rp = a["rank_pass_s"]
+    assert len(rp["all"]) == 8 and rp["min"] <= rp["max"] and rp["all"][rp["argmax"]] == rp["max"] and abs(rp["max"] * 1e3 - a["ms_per_step"]) < 0.02
 
 
 def test_a_failing_rank_other_than_zero_fails_the_launcher():
@@ -87,6 +93,17 @@ def test_a_failing_rank_other_than_zero_fails_the_launcher():
     the exchange step - the launcher must end them and exit 9, with no JSON line."""
     r = _bench(["--gpus", "8", "--poses", "8", "--hypo", "3", "--oil", "10"], share=True, extra_env={"ZEDO_BENCH_FAIL_RANK": "5"}, ok=False)
     assert r.returncode == 9 and "rank 5 exited with code 9" in r.stderr, (r.returncode, r.stderr[-2000:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("workload", ["2", "4"])
+def test_a_corrupted_shard_fails_the_selfcheck_before_anything_is_timed(workload):
+    """ZEDO_BENCH_CORRUPT_RANK=3: rank 3 of 8 moves its shard by a millimetre before the exchange step of the self-check; the
+    sharded digest then differs from rank 0's unsharded one, every rank exits with code 4 and no JSON line is printed - a
+    wrong N-rank result cannot yield a number (selection exchange and the all-gather of run.inference alike)."""
+    r = _bench(["--gpus", "8", "--workload", workload, "--poses", "8", "--hypo", "3", "--oil", "10"], share=True,
+               extra_env={"ZEDO_BENCH_CORRUPT_RANK": "3"}, ok=False)
+    assert r.returncode == 4 and "multi_rank_selfcheck FAILED" in r.stderr, (r.returncode, r.stderr[-2000:])
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 

@@ -178,12 +178,12 @@ extern "C" int zedo_profile_stop(double *h_total_ms, long long *h_samples, long 
 }
 
 static size_t chunk_rows_cap() {
-    static size_t cap = 0;
-    if (!cap) {
+    // read once; a function-local static is initialised exactly once even when several host threads make their first call together
+    static const size_t cap = [] {
         const char *e = getenv("ZEDO_CHUNK_ROWS");
-        long v = e ? atol(e) : 0;
-        cap = v > 0 ? (size_t)round_up((int)v, ROW_PAD) : (size_t)1 << 20;
-    }
+        const long v = e ? atol(e) : 0;
+        return v > 0 ? (size_t)round_up((int)v, ROW_PAD) : (size_t)1 << 20;
+    }();
     return cap;
 }
 

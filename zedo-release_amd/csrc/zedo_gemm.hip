@@ -472,7 +472,8 @@ __global__ __launch_bounds__(WM *WN * 64, WPE) void layer_kernel(LayerArgs a) {
 }
 
 // One launch, two tile shapes: workgroups [0, nbig) run 128x128 tiles on the rows that fill whole rounds of the
-// chip, workgroups [nbig, grid) run 32x128 tiles on the remainder rows.  Workgroups are dispatched in order, so the
+// chip, workgroups [nbig, grid) run 64x64 (four-wave layers; until round 3: 32x128) / 64x128 (eight-wave layers) tiles on the
+// remainder rows.  Workgroups are dispatched in order, so the
 // small tiles start as CUs run out of big tiles and fill the tail of the launch instead of costing a separate,
 // latency-bound launch (40 us -> ~26 us per layer at 50 750 rows).  Both shapes of a launch use the same block size.
 #ifndef ZEDO_SCHED_BIG
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(WM *WN * 64, WPE) void layer_kernel(LayerArgs a) {
 #endif
 constexpr int SCHED_BIG = ZEDO_SCHED_BIG, SCHED_SMALL = ZEDO_SCHED_SMALL, SCHED_THIN = ZEDO_SCHED_THIN;
 
-// W8 = 0: 4 waves per workgroup (64x64 per wave; remainder in 32x128 tiles); W8 = 1: 8 waves (64x32 per wave, 82
+// W8 = 0: 4 waves per workgroup (64x64 per wave; remainder in 64x64 tiles); W8 = 1: 8 waves (64x32 per wave, 82
 // registers, four waves per SIMD; remainder in 64x128 tiles) - measured faster for the residual epilogue, whose
 // residual DMA + wait has more co-resident waves to hide behind.
 #ifndef ZEDO_PAIR_W8_PLAIN

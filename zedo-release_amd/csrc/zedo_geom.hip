@@ -352,9 +352,20 @@ struct IpoKeys { int j[IPO_KMAX]; };   // IPO_keylist travels as a kernel argume
 // step_size = lr / (1 - beta1^t) and sqrt(1 - beta2^t) of torch.optim.Adam for t = 1 .. IPO_TABLE, formed on the host by
 // the statements the kernel itself uses beyond the table (running double products, one division, one square root:
 // correctly rounded on both sides, so the table changes no bit) - two double-precision long-latency operations per
-// iteration that every lane of the fit would otherwise repeat.
-__constant__ float c_adam_step[IPO_TABLE];
-__constant__ float c_adam_bc2s[IPO_TABLE];
+// iteration that every lane of the fit would otherwise repeat.  The table is part of the code object: the Makefile runs
+// gen_adam_table.cpp (those statements, on the build host) into zedo_adam_table.inc as exact hexadecimal float literals.  No
+// upload at run time: the first zedo_ipo_fit of a device neither blocks nor races with a fit on another stream or host thread,
+// and is legal under stream capture (rounds 1-4 copied the table to the symbol inside the first fit).
+__constant__ float c_adam_step[IPO_TABLE] = {
+#define ZEDO_ADAM_STEP
+#include "zedo_adam_table.inc"
+#undef ZEDO_ADAM_STEP
+};
+__constant__ float c_adam_bc2s[IPO_TABLE] = {
+#define ZEDO_ADAM_BC2S
+#include "zedo_adam_table.inc"
+#undef ZEDO_ADAM_BC2S
+};
 
 // Sum over the 32 lanes of a half-wave in ONE fixed order: four pairing levels inside each 16-lane row as DPP operand
 // modifiers of the add itself (row_mirror: i <-> 15 - i, row_half_mirror: i <-> 7 - i, quad_perm xor 2, quad_perm xor 1 - no
@@ -670,34 +681,11 @@ __global__ __launch_bounds__(IPO_ROW_TB) void ipo_row_kernel(const float *__rest
 #undef IPO_SLOT_ARGS
 #undef IPO_SLOT_PARAMS
 
-// the Adam table of this device, once (a blocking copy: the only synchronising step of the first fit on a device)
-static hipError_t ensure_adam_table() {
-    static std::atomic<bool> done[MAX_DEVICES];
-    const int slot = device_slot();
-    if (slot >= 0 && done[slot].load(std::memory_order_acquire)) return hipSuccess;
-    static float h_step[IPO_TABLE], h_bc2s[IPO_TABLE];
-    static std::atomic<bool> host_ready{false};
-    if (!host_ready.load(std::memory_order_acquire)) {
-        double b1p = 1.0, b2p = 1.0;
-        for (int t = 0; t < IPO_TABLE; ++t) {
-            b1p *= 0.9; b2p *= 0.999;
-            h_step[t] = (float)(0.1 / (1.0 - b1p));
-            h_bc2s[t] = (float)sqrt(1.0 - b2p);
-        }
-        host_ready.store(true, std::memory_order_release);   // a racing thread writes the same values
-    }
-    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_adam_step), h_step, sizeof(h_step));
-    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_adam_bc2s), h_bc2s, sizeof(h_bc2s));
-    if (e == hipSuccess && slot >= 0) done[slot].store(true, std::memory_order_release);
-    return e;
-}
-
 hipError_t launch_ipo_fit(const float *x0, const float *uv, const float *K, const int *h_keylist, int k,
                           int axes_mask, float ipo_T, float min_scale, float max_scale, int iters,
                           double normaliser, float *R, float *T, float *q, float *scale, float *state, int it_begin,
                           int B, int N, int J, long long row_offset, hipStream_t st) {
     if (k < 1 || k > IPO_KMAX) return hipErrorInvalidValue;
-    if (hipError_t e = ensure_adam_table(); e != hipSuccess) return e;
     double b1p0 = 1.0, b2p0 = 1.0;
     for (int i = 0; i < it_begin; ++i) { b1p0 *= 0.9; b2p0 *= 0.999; }   // the same running products the kernel forms
     IpoKeys keys{};
@@ -708,7 +696,8 @@ hipError_t launch_ipo_fit(const float *x0, const float *uv, const float *K, cons
     // the choice may depend on the LOCAL row count without breaking shard invariance.  ZEDO_IPO_KERNEL=half|row pins it.
     static const char *pin = getenv("ZEDO_IPO_KERNEL");
     const bool has_row = (k == 3 || k == 17);
-    bool row = has_row && B >= (k == 17 ? 17408 : 4096);
+    // crossover in rows per CU of the CURRENT device (measured on 256 CUs: 17 408 rows with 17 key joints, 4 096 with 3)
+    bool row = has_row && B >= num_cus() * (k == 17 ? 68 : 16);
     if (pin && pin[0] == 'h') row = false;
     if (pin && pin[0] == 'r' && has_row) row = true;
     const float inv_norm = (float)(1.0 / normaliser);

@@ -44,10 +44,13 @@ def hypothesis_min(preds, gt_centred, protocol2, valid_ind=None, row_offset=0, d
 def valid_rows_mask(valid_ind, N, row_offset, B, device):
     """bool [B] on `device`: row g = row_offset + i (g = h*N + n) is True when hypothesis h is listed in valid_ind[n].
     One flat index list built on the host (no per-pose Python statement: the full H36M test set has 567 040 poses) and
-    ONE scatter on the device."""
+    ONE scatter on the device.  The container contract is the reference's own - `valid_ind[idx]` supports `in` / iteration
+    (h36m.py:400 `sec_idx not in valid_ind[idx]`) - so a list, a tuple, an array of lists or a mapping {pose index: [...]}
+    all work: the entries are fetched BY INDEX 0 .. N-1, never by iterating the container itself."""
     import itertools
-    lens = np.fromiter((len(v) for v in valid_ind), dtype=np.int64, count=N)
-    h = np.fromiter(itertools.chain.from_iterable(valid_ind), dtype=np.int64, count=int(lens.sum()))
+    per_pose = [valid_ind[n] if isinstance(valid_ind[n], (list, tuple, np.ndarray)) else list(valid_ind[n]) for n in range(N)]
+    lens = np.fromiter((len(v) for v in per_pose), dtype=np.int64, count=N)
+    h = np.fromiter(itertools.chain.from_iterable(per_pose), dtype=np.int64, count=int(lens.sum()))
     g = h * N + np.repeat(np.arange(N, dtype=np.int64), lens) - int(row_offset)
     g = g[(h >= 0) & (g >= 0) & (g < B)]
     ok = torch.zeros((B,), dtype=torch.bool, device=device)

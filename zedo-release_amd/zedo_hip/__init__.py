@@ -11,10 +11,23 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-import sys as _sys
-if os.path.dirname(_HERE) not in _sys.path:
-    _sys.path.insert(0, os.path.dirname(_HERE))
-import zedo_build as _zb
+
+
+def _load_zedo_build():
+    """zedo_build.py sits beside this package; it is loaded BY LOCATION so that importing zedo_hip never edits sys.path
+    (the package root also holds the generic top-level names `lib` and `run`, which must not shadow a host application's)."""
+    import importlib.util
+    import sys
+    if "zedo_build" in sys.modules:
+        return sys.modules["zedo_build"]
+    spec = importlib.util.spec_from_file_location("zedo_build", os.path.join(os.path.dirname(_HERE), "zedo_build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["zedo_build"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_zb = _load_zedo_build()
 
 # Not a fallback: the only way to get the hot path is to compile the HIP sources (hipcc cross-compiles gfx950 without a
 # GPU).  A missing library is built once, under a lock (N ranks importing at the same time build it once); with
@@ -95,8 +108,46 @@ def _p(t, dtype=torch.float32):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+# ---- streams, devices, threads ------------------------------------------------------------------------------------------
+# The C ABI is re-entrant across distinct streams (include/zedo_hip.h); this mirror honours that: every call is
+# enqueued on the CURRENT stream of the device its tensors live on (not of whatever device happens to be current), runs
+# with that device current (the library's per-device launch state follows hipGetDevice), takes its workspace from torch's
+# stream-aware caching allocator per call - so two streams or two host threads never share scratch memory, and a block is
+# only handed out again in stream order - and refuses arguments that live on different devices.
+def _device_of(*objs):
+    """The one CUDA device of the given tensors / handles (None entries skipped); mixed devices are an error."""
+    dev = None
+    for o in objs:
+        if o is None:
+            continue
+        d = o.device if isinstance(o, (torch.Tensor, Weights, Schedule)) else None
+        if d is None:
+            continue
+        d = torch.device(d)
+        if d.type != "cuda":
+            raise ZedoError(f"expected CUDA tensors, got one on {d}")
+        if d.index is None:
+            d = torch.device("cuda", torch.cuda.current_device())
+        if dev is None:
+            dev = d
+        elif d != dev:
+            raise ZedoError(f"arguments live on different devices ({dev} and {d}): one call runs on one GPU")
+    if dev is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def _norm_device(device=None):
+    """torch.device("cuda", index) for `device` (None / "cuda" = the current device)."""
+    d = torch.device("cuda") if device is None else torch.device(device)
+    if d.type != "cuda":
+        raise ZedoError(f"libzedo_hip runs on CUDA (HIP) devices only, not on {d}")
+    return torch.device("cuda", torch.cuda.current_device()) if d.index is None else d
+
+
+def _stream(device=None):
+    """hipStream_t of torch's current stream ON `device` (default: the current device)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def abi_version():
@@ -131,8 +182,9 @@ class Weights:
     math: "f32" | "f16x3" | None (= default_math(), i.e. the ZEDO_MATH environment variable)."""
 
     def __init__(self, state_dict, n_joints=N_JOINTS, joint_dim=JOINT_DIM, hidden=HIDDEN_DIM, embed=EMBED_DIM,
-                 n_blocks=2, math=None):
+                 n_blocks=2, math=None, device=None):
         _need_gpu()
+        self.device = _norm_device(device)
         flat = []
         for name in param_names(n_blocks):
             v = state_dict[name]
@@ -141,15 +193,18 @@ class Weights:
             flat.append(np.ascontiguousarray(v, dtype=np.float32).reshape(-1))
         flat = np.concatenate(flat)
         self._h = ctypes.c_void_p()
-        _check(_lib.zedo_weights_create(flat.ctypes.data_as(_vp), flat.size, n_joints, joint_dim, hidden, embed,
-                                        n_blocks, _stream(), ctypes.byref(self._h)))
+        with torch.cuda.device(self.device):
+            _check(_lib.zedo_weights_create(flat.ctypes.data_as(_vp), flat.size, n_joints, joint_dim, hidden, embed,
+                                            n_blocks, _stream(self.device), ctypes.byref(self._h)))
         self.n_joints, self.joint_dim, self.hidden, self.embed, self.n_blocks = n_joints, joint_dim, hidden, embed, n_blocks
         self.set_math(default_math() if math is None else math)
 
     def set_math(self, math):
+        """Not re-entrant with calls that use this handle: switch modes between runs, not during them."""
         if math not in MATH_MODES:
             raise ZedoError(f"math mode {math!r}: expected one of {sorted(MATH_MODES)}")
-        _check(_lib.zedo_weights_set_math(self._h, MATH_MODES[math], _stream()))
+        with torch.cuda.device(self.device):
+            _check(_lib.zedo_weights_set_math(self._h, MATH_MODES[math], _stream(self.device)))
         self.math = math
         return self
 
@@ -169,9 +224,11 @@ class Schedule:
         self.S = int(ts.size)
         self.ts = ts
         self.weights = weights  # keep alive
+        self.device = weights.device
         self._h = ctypes.c_void_p()
-        _check(_lib.zedo_schedule_create(weights._h, ts.ctypes.data_as(_vp), self.S, label_scale, beta_min, beta_max,
-                                         n_sde, _stream(), ctypes.byref(self._h)))
+        with torch.cuda.device(self.device):
+            _check(_lib.zedo_schedule_create(weights._h, ts.ctypes.data_as(_vp), self.S, label_scale, beta_min, beta_max,
+                                             n_sde, _stream(self.device), ctypes.byref(self._h)))
 
     def read(self):
         nl = 1 + 2 * self.weights.n_blocks
@@ -192,36 +249,35 @@ def workspace_bytes(B):
     return int(_lib.zedo_workspace_bytes(int(B)))
 
 
-_ws_cache = {}
-
-
 def workspace(B, device=None):
-    """A cached uint8 CUDA tensor large enough for B rows."""
+    """A uint8 CUDA tensor large enough for B rows, owned by the CALL that asked for it: a fresh block of torch's caching
+    allocator, tagged with the current stream of `device` (so the allocator re-issues it only in stream order once the call's
+    reference is gone - the kernels of the call may still be running then) and shared with no other stream or thread.  After
+    the first call of a size the block comes out of the allocator's cache: microseconds, no hipMalloc."""
     _need_gpu()
-    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    need = workspace_bytes(B)
-    cur = _ws_cache.get(device)
-    if cur is None or cur.numel() < need:
-        _ws_cache[device] = None
-        cur = torch.empty(need, dtype=torch.uint8, device=device)
-        _ws_cache[device] = cur
-    return cur
+    device = _norm_device(device)
+    with torch.cuda.device(device):
+        return torch.empty(workspace_bytes(B), dtype=torch.uint8, device=device)
 
 
 def reproj_prepare(uv, K, conf=None, conf_clamped_out=None):
     """uv [N,J,2], K [N,3,3], conf [N,J] or None -> geom [N,J,8]."""
     _need_gpu()
+    dev = _device_of(uv, K, conf, conf_clamped_out)
     N, J = uv.shape[0], uv.shape[1]
-    geom = torch.empty((N, J, GEOM_F), dtype=torch.float32, device=uv.device)
-    _check(_lib.zedo_reproj_prepare(_p(uv), _p(K), _p(conf), N, J, _p(geom), _p(conf_clamped_out), _stream()))
+    with torch.cuda.device(dev):
+        geom = torch.empty((N, J, GEOM_F), dtype=torch.float32, device=dev)
+        _check(_lib.zedo_reproj_prepare(_p(uv), _p(K), _p(conf), N, J, _p(geom), _p(conf_clamped_out), _stream(dev)))
     return geom
 
 
 def reproj_degenerate(geom):
     """Number of poses whose least-squares system for T is singular (zedo_reproj_degenerate; synchronises)."""
     _need_gpu()
+    dev = _device_of(geom)
     n = ctypes.c_int(0)
-    _check(_lib.zedo_reproj_degenerate(_p(geom), geom.shape[0], geom.shape[1], ctypes.cast(ctypes.byref(n), _vp), _stream()))
+    with torch.cuda.device(dev):
+        _check(_lib.zedo_reproj_degenerate(_p(geom), geom.shape[0], geom.shape[1], ctypes.cast(ctypes.byref(n), _vp), _stream(dev)))
     return int(n.value)
 
 
@@ -232,40 +288,48 @@ SINGULAR_MSG = ("gradient_field_gen: the least-squares system for T is singular 
 def reproj_grad(x, geom, T, solve_T, row_offset=0):
     """gradient_field_gen body: returns g [B,J,3]; T [B,3] is overwritten when solve_T."""
     _need_gpu()
+    dev = _device_of(x, geom, T)
     B, J = x.shape[0], x.shape[1]
-    g = torch.empty_like(x)
-    _check(_lib.zedo_reproj_grad(_p(x), _p(geom), _p(T), int(bool(solve_T)), _p(g), B, geom.shape[0], J,
-                                 int(row_offset), _stream()))
+    with torch.cuda.device(dev):
+        g = torch.empty_like(x)
+        _check(_lib.zedo_reproj_grad(_p(x), _p(geom), _p(T), int(bool(solve_T)), _p(g), B, geom.shape[0], J,
+                                     int(row_offset), _stream(dev)))
     return g
 
 
 def score_eps(weights, sched, step, x):
     _need_gpu()
+    dev = _device_of(weights, sched, x)
     B = x.shape[0]
-    ws = workspace(B, x.device)
-    eps = torch.empty_like(x)
-    _check(_lib.zedo_score_eps(weights._h, sched._h, int(step), _p(x), _p(eps), B, _p(ws, torch.uint8), ws.numel(),
-                               _stream()))
+    with torch.cuda.device(dev):
+        ws = workspace(B, dev)
+        eps = torch.empty_like(x)
+        _check(_lib.zedo_score_eps(weights._h, sched._h, int(step), _p(x), _p(eps), B, _p(ws, torch.uint8), ws.numel(),
+                                   _stream(dev)))
     return eps
 
 
 def sde_step(weights, sched, step, x):
     """x <- a x + c eps(x), in place."""
     _need_gpu()
+    dev = _device_of(weights, sched, x)
     B = x.shape[0]
-    ws = workspace(B, x.device)
-    _check(_lib.zedo_sde_step(weights._h, sched._h, int(step), _p(x), B, _p(ws, torch.uint8), ws.numel(), _stream()))
+    with torch.cuda.device(dev):
+        ws = workspace(B, dev)
+        _check(_lib.zedo_sde_step(weights._h, sched._h, int(step), _p(x), B, _p(ws, torch.uint8), ws.numel(), _stream(dev)))
     return x
 
 
 def oil_run(weights, sched, x, geom, T, step_begin, step_end, switch_step, row_offset=0):
     """Fused OIL loop over steps [step_begin, step_end); x [B,J,3] and T [B,3] updated in place."""
     _need_gpu()
+    dev = _device_of(weights, sched, x, geom, T)
     B = x.shape[0]
-    ws = workspace(B, x.device)
-    _check(_lib.zedo_oil_run(weights._h, sched._h, _p(x), _p(geom), _p(T), int(step_begin), int(step_end),
-                             int(switch_step), B, geom.shape[0], int(row_offset), _p(ws, torch.uint8), ws.numel(),
-                             _stream()))
+    with torch.cuda.device(dev):
+        ws = workspace(B, dev)
+        _check(_lib.zedo_oil_run(weights._h, sched._h, _p(x), _p(geom), _p(T), int(step_begin), int(step_end),
+                                 int(switch_step), B, geom.shape[0], int(row_offset), _p(ws, torch.uint8), ws.numel(),
+                                 _stream(dev)))
     return x, T
 
 
@@ -278,52 +342,59 @@ def ipo_fit(x0, uv, K, keylist, axes, ipo_T, min_scale, max_scale, iters, normal
     """x0 [H,J,3] centred cluster poses, uv [N,J,2], K [N,3,3] -> R [B,3,3], T [B,3] (, q [B,4], scale [B]).
     state [B,15] (optional, in/out) + it_begin: resume from a captured Adam state (zedo_ipo_fit_resume)."""
     _need_gpu()
+    dev = _device_of(x0, uv, K, state)
     N, J, H = uv.shape[0], uv.shape[1], x0.shape[0]
-    dev = uv.device
-    R = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
-    T = torch.empty((B, 3), dtype=torch.float32, device=dev)
-    q = torch.empty((B, 4), dtype=torch.float32, device=dev) if return_params else None
-    sc = torch.empty((B,), dtype=torch.float32, device=dev) if return_params else None
     kl = (ctypes.c_int * len(keylist))(*[int(k) for k in keylist])
-    if state is not None:
-        _check(_lib.zedo_ipo_fit_resume(_p(x0), _p(uv), _p(K), ctypes.cast(kl, _vp), len(keylist), axes_mask(axes),
-                                        float(ipo_T), float(min_scale), float(max_scale), int(iters), float(normaliser),
-                                        _p(R), _p(T), _p(q), _p(sc), _p(state), int(it_begin), B, H, N, J,
-                                        int(row_offset), _stream()))
-    else:
-        _check(_lib.zedo_ipo_fit(_p(x0), _p(uv), _p(K), ctypes.cast(kl, _vp), len(keylist), axes_mask(axes),
-                                 float(ipo_T), float(min_scale), float(max_scale), int(iters), float(normaliser),
-                                 _p(R), _p(T), _p(q), _p(sc), B, H, N, J, int(row_offset), _stream()))
+    with torch.cuda.device(dev):
+        R = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
+        T = torch.empty((B, 3), dtype=torch.float32, device=dev)
+        q = torch.empty((B, 4), dtype=torch.float32, device=dev) if return_params else None
+        sc = torch.empty((B,), dtype=torch.float32, device=dev) if return_params else None
+        if state is not None:
+            _check(_lib.zedo_ipo_fit_resume(_p(x0), _p(uv), _p(K), ctypes.cast(kl, _vp), len(keylist), axes_mask(axes),
+                                            float(ipo_T), float(min_scale), float(max_scale), int(iters), float(normaliser),
+                                            _p(R), _p(T), _p(q), _p(sc), _p(state), int(it_begin), B, H, N, J,
+                                            int(row_offset), _stream(dev)))
+        else:
+            _check(_lib.zedo_ipo_fit(_p(x0), _p(uv), _p(K), ctypes.cast(kl, _vp), len(keylist), axes_mask(axes),
+                                     float(ipo_T), float(min_scale), float(max_scale), int(iters), float(normaliser),
+                                     _p(R), _p(T), _p(q), _p(sc), B, H, N, J, int(row_offset), _stream(dev)))
     return (R, T, q, sc) if return_params else (R, T)
 
 
 def rotate_init(x0, R, N, row_offset=0):
     _need_gpu()
+    dev = _device_of(x0, R)
     B, J = R.shape[0], x0.shape[1]
-    x = torch.empty((B, J, 3), dtype=torch.float32, device=R.device)
-    _check(_lib.zedo_rotate_init(_p(x0), _p(R), _p(x), B, x0.shape[0], N, J, int(row_offset), _stream()))
+    with torch.cuda.device(dev):
+        x = torch.empty((B, J, 3), dtype=torch.float32, device=dev)
+        _check(_lib.zedo_rotate_init(_p(x0), _p(R), _p(x), B, x0.shape[0], N, J, int(row_offset), _stream(dev)))
     return x
 
 
 def min_mpjpe(pred, gt_centred, N, procrustes=False, row_offset=0):
     """pred [B,J,3] fp32 rows (h,n); gt_centred [N,J,3] float64 -> (err [B], best [N], best_h [N])."""
     _need_gpu()
+    dev = _device_of(pred, gt_centred)
     B, J = pred.shape[0], pred.shape[1]
-    err = torch.empty((B,), dtype=torch.float64, device=pred.device)
-    best = torch.empty((N,), dtype=torch.float64, device=pred.device)
-    best_h = torch.empty((N,), dtype=torch.int32, device=pred.device)
-    _check(_lib.zedo_min_mpjpe(_p(pred), _p(gt_centred, torch.float64), B, N, J, int(row_offset), int(bool(procrustes)),
-                               _p(err, torch.float64), _p(best, torch.float64), _p(best_h, torch.int32), _stream()))
+    with torch.cuda.device(dev):
+        err = torch.empty((B,), dtype=torch.float64, device=dev)
+        best = torch.empty((N,), dtype=torch.float64, device=dev)
+        best_h = torch.empty((N,), dtype=torch.int32, device=dev)
+        _check(_lib.zedo_min_mpjpe(_p(pred), _p(gt_centred, torch.float64), B, N, J, int(row_offset), int(bool(procrustes)),
+                                   _p(err, torch.float64), _p(best, torch.float64), _p(best_h, torch.int32), _stream(dev)))
     return err, best, best_h
 
 
 def pose_min(err, N, row_offset=0):
     """Per-pose minimum / first arg-min over the hypotheses of the (possibly edited) per-row errors (zedo_pose_min)."""
     _need_gpu()
-    best = torch.empty((N,), dtype=torch.float64, device=err.device)
-    best_h = torch.empty((N,), dtype=torch.int32, device=err.device)
-    _check(_lib.zedo_pose_min(_p(err, torch.float64), err.shape[0], N, int(row_offset), _p(best, torch.float64),
-                              _p(best_h, torch.int32), _stream()))
+    dev = _device_of(err)
+    with torch.cuda.device(dev):
+        best = torch.empty((N,), dtype=torch.float64, device=dev)
+        best_h = torch.empty((N,), dtype=torch.int32, device=dev)
+        _check(_lib.zedo_pose_min(_p(err, torch.float64), err.shape[0], N, int(row_offset), _p(best, torch.float64),
+                                  _p(best_h, torch.int32), _stream(dev)))
     return best, best_h
 
 
