@@ -268,7 +268,10 @@ def test_ipo_trajectory_golden(zh, golden, N, axes, kname):
         rows.append(dict(it=it, hip_vs_ref64=float(dp.max()), hip_vs_ref32=float(d32), ref32_vs_ref64=float(gp.max()),
                          hip_vs_ref64_median=float(np.median(dp)), ref32_vs_ref64_median=float(np.median(gp)),
                          hip_vs_ref64_p90=float(np.percentile(dp, 90)), ref32_vs_ref64_p90=float(np.percentile(gp, 90)),
-                         poses_beyond_2_gaps=int((dp > 2.0 * gp + 1e-6).sum()), poses=int(len(dp))))
+                         poses_beyond_2_gaps=int((dp > 2.0 * gp + 1e-6).sum()), poses=int(len(dp)),
+                         # the pose the REFERENCE's own fp32 run is farthest from its fp64 run on, and everybody else
+                         ref_worst_pose=int(np.argmax(gp)), hip_at_ref_worst_pose=float(dp[int(np.argmax(gp))]),
+                         hip_other_poses=float(np.delete(dp, int(np.argmax(gp))).max()) if len(dp) > 1 else 0.0))
     _report(f"ipo_{tag}", rows)
     for r in rows:
         if r["it"] <= 30:
@@ -276,10 +279,13 @@ def test_ipo_trajectory_golden(zh, golden, N, axes, kname):
             # on, in the reference's fp32 run and here alike (64 poses, xyz, 17 joints: reference 0.25 -> 0.54 -> 1.5 ->
             # 3.9 e-6 at iterations 2 / 5 / 8 / 10, kernel 0.27 -> 0.70 -> 3.4 -> 8.0): the same unstable mode excited by
             # two different first roundings.  A ratio of two such amplitudes says nothing at a factor of 2 (round 3's
-            # sequential joint sum drew 1.7, round 4's half-wave butterfly 2.3), so the worst pose is held to 4 gaps and
-            # the BULK gets a bound of its own: the median pose within 1.5 x the reference's median gap (measured over the
-            # eight cases: worst pose 0.57 ... 2.25 gaps, median pose 0.85 ... 1.35 x the reference's median).
-            assert r["hip_vs_ref64"] <= 4.0 * r["ref32_vs_ref64"] + 1e-7, {k: r[k] for k in ("it", "hip_vs_ref64", "ref32_vs_ref64")}
+            # sequential joint sum drew 1.7, round 4's half-wave butterfly 2.3), so THAT pose - identified by the reference
+            # itself: the pose its own fp32 run is farthest from its fp64 run on - is held to 4 gaps, every OTHER pose to the
+            # 2 gaps of rounds 1-3 (round 4 had relaxed all poses to 4), and the BULK gets a bound of its own: the
+            # median pose within 1.5 x the reference's median gap (measured over the eight cases: worst pose 0.57 ... 2.25
+            # gaps, median pose 0.85 ... 1.35 x the reference's median).
+            assert r["hip_at_ref_worst_pose"] <= 4.0 * r["ref32_vs_ref64"] + 1e-7, {k: r[k] for k in ("it", "ref_worst_pose", "hip_at_ref_worst_pose", "ref32_vs_ref64")}
+            assert r["hip_other_poses"] <= 2.0 * r["ref32_vs_ref64"] + 1e-7, {k: r[k] for k in ("it", "ref_worst_pose", "hip_other_poses", "ref32_vs_ref64")}
             assert r["hip_vs_ref64_median"] <= 1.5 * r["ref32_vs_ref64_median"] + 2e-8, {k: r[k] for k in ("it", "hip_vs_ref64_median", "ref32_vs_ref64_median")}
         else:
             assert r["hip_vs_ref64_median"] <= 2.0 * r["ref32_vs_ref64_median"] + 1e-7 and r["hip_vs_ref64"] <= 0.1, r

@@ -7,7 +7,13 @@ the 0.05 mm bar and drowns the comparison of the 1000-step loop.  Here the loop 
 reference's run produced them (tests/golden/<capture>_ipo.npz: float32, bit for bit, tools/gen_golden.py::
 _driver_ipo_pin) through zedo_rotate_init + zedo_oil_run, all 50 750 rows x 1000 steps, and the dataset means are held to
 the north-star bar DIRECTLY: |MPJPE - reference| <= 0.05 mm and |PA-MPJPE - reference| <= 0.05 mm, no standard-error
-escape (reference loop: run/opt_main.py:197-222)."""
+escape (reference loop: run/opt_main.py:197-222).
+
+Round 5: the dataset means are not the only assertion any more.  A mean over 50 750 rows forgives what moves rows in both
+directions - the mutation table showed the conf^4 -> conf^2 mutant of the least-squares weight (simple_zeroshot_opt.py:73-93)
+passing the means on the draw with uniform confidences.  tests/golden/<capture>_oil64.npz holds the reference's loop re-run in
+FLOAT64 from the same (R, T); every row's error is held against it: the HIP loop's distance from exact arithmetic must be no
+larger than the reference's own fp32 loop's - median <= 1.0 x, p90 and p99 <= 1.25 x - on every capture and both protocols."""
 import json
 import os
 
@@ -77,7 +83,8 @@ def test_oil_loop_from_the_reference_ipo_output_meets_the_bar(weights0, golden, 
            "pa_hip": p2, "pa_ref": float(g["pa_mpjpe"]), "d_mpjpe_mm": (p1 - float(g["mpjpe"])) * 1e3,
            "d_pa_mpjpe_mm": (p2 - float(g["pa_mpjpe"])) * 1e3}
     gt = torch.as_tensor(gtc, device="cuda")
-    arb = golden(name + "_oil64") if os.path.exists(os.path.join(ROOT, "tests", "golden", name + "_oil64.npz")) else None
+    assert os.path.exists(os.path.join(ROOT, "tests", "golden", name + "_oil64.npz")), "the float64-loop arbiter of this capture is missing"
+    arb = golden(name + "_oil64")
     for key, proto in (("p1", False), ("p2", True)):
         err, best, idx = zh.min_mpjpe(x, gt, N, procrustes=proto)
         e = err.reshape(H, N).T.cpu().numpy()                               # [N, H]
@@ -104,3 +111,10 @@ def test_oil_loop_from_the_reference_ipo_output_meets_the_bar(weights0, golden, 
     print(json.dumps(rep))
     assert abs(rep["d_mpjpe_mm"]) <= BAR_MM, rep
     assert abs(rep["d_pa_mpjpe_mm"]) <= BAR_MM, rep
+    # per row, against the float64 loop: not farther from exact arithmetic than the reference's own fp32 loop
+    # (measured round 4: median 0.76-0.85 x, p90 0.90-1.12 x, p99 0.84-1.22 x for MPJPE; 0.43-0.47 x throughout for PA-MPJPE)
+    for key in ("p1", "p2"):
+        v = rep[key]["vs_fp64_loop_mm"]
+        h, r = v["hip"], v["reference_fp32"]
+        assert h["median"] <= 1.0 * r["median"], (name, key, h, r)
+        assert h["p90"] <= 1.25 * r["p90"] and h["p99"] <= 1.25 * r["p99"], (name, key, h, r)

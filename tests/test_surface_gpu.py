@@ -195,12 +195,19 @@ def test_fused_driver_full_length_matches_reference(weights0, golden):
     e_ref = np.linalg.norm(ref.astype(np.float64) - gtc[:, None], axis=-1).mean(-1).min(1)
     assert abs(e_ref.mean() - float(d["mpjpe"])) < 1e-6
     env = golden("driver_full_env")
-    ref_runs = np.concatenate([[float(d["mpjpe"])], env["mpjpe"]])
-    envelope = float(ref_runs.max() - ref_runs.min())
+    ref_runs = np.concatenate([[float(d["mpjpe"])], env["mpjpe"]]) * 1e3                       # mm, the reference's seven runs
+    from scipy import stats
+    Kr = len(ref_runs)
+    # the reference's seven means are six tight ones (robust sd 0.06 mm) and one 0.72 mm above their median: ONE fit of the 480
+    # in another basin moves a 160-pose mean by that much.  The bound on the mean is a t prediction interval from all seven runs
+    # (heavy tail included; the max - min of round 4 is gone), the real instrument is the per-pose decomposition below
+    half = float(stats.t.ppf(0.975, Kr - 1) * ref_runs.std(ddof=1) * np.sqrt(1 + 1 / Kr))
+    flip_mm = float(len(e_ref) * (ref_runs.max() - np.median(ref_runs)))                       # the reference's own largest single-fit event, per pose
     with open("gpurun_out/parity_report.jsonl", "a") as f:
-        f.write(json.dumps({"test": "driver_full_envelope", "d_mpjpe_mm": (p1 - float(d["mpjpe"])) * 1e3, "reference_self_envelope_mm": envelope * 1e3,
-                            "reference_runs_mm": [float(v) * 1e3 for v in ref_runs]}) + "\n")
-    assert abs(p1 - float(d["mpjpe"])) <= max(5e-5, envelope), (p1, float(d["mpjpe"]), envelope)
+        f.write(json.dumps({"test": "driver_full_envelope", "d_mpjpe_vs_reference_mean_mm": p1 * 1e3 - float(ref_runs.mean()),
+                            "prediction_interval_half_width_mm": half, "reference_largest_single_event_mm": flip_mm,
+                            "reference_runs_mm": [float(v) for v in ref_runs]}) + "\n")
+    assert abs(p1 * 1e3 - ref_runs.mean()) <= max(0.05, half), (p1, ref_runs, half)
     assert np.abs(env["pa_mpjpe"] - float(d["pa_mpjpe"])).max() < 5e-5          # the reference against itself meets the bar in PA-MPJPE
     # WHERE the difference of the means sits (round 4): in 160 best-of-3 values it is two or three single fits that land in
     # another basin - with round 4's kernels pose 147 (hypothesis 1: 1670.5 mm here, 1590.3 mm in the reference and in the numpy
@@ -220,6 +227,10 @@ def test_fused_driver_full_length_matches_reference(weights0, golden):
                             "median_abs_mm": float(np.median(np.abs(dpose)))}) + "\n")
     assert int((np.abs(dpose) > 20).sum()) <= k, dpose[order[:6]]
     assert abs(rest.mean()) <= 0.05, (rest.mean(), dpose[order[:6]])
+    # the excluded 2 % are bounded too: a fit in another basin may move its pose by what the reference's OWN runs
+    # show such an event to be worth - one of its seven runs sits 0.72 mm x 160 poses = 115 mm of per-pose error above the
+    # others - times 1.5; a pose farther off than that is not a basin flip the reference knows
+    assert np.abs(dpose[order[:k]]).max() <= 1.5 * flip_mm, (dpose[order[:k]], flip_mm)
 
 
 def test_reference_loop_through_the_per_step_surface(model, weights0):
@@ -287,9 +298,9 @@ def test_fused_driver_at_baseline_size_matches_reference(weights0, golden, name)
     weights (tools/gen_golden.py::gen_driver_h36m_full / gen_driver_pw3d_full; the inputs are regenerated from the
     committed seeds and checked against the fixture's hash; driver_pw3d_full_b is a second, independent draw of
     configs[2]'s shape - other poses and clusters, confidence 1 - so that a bias could be told from a fluctuation).  Bar (BASELINE.json north_star): dataset-mean MPJPE and
-    PA-MPJPE within 0.05 mm - PA-MPJPE outright, MPJPE within max(0.05 mm, the reference's own fp32 self-envelope): the largest
-    difference between two of the REFERENCE's runs of the same problem on detections that differ by one ulp (tests/golden/
-    driver_pw3d_full*_env*.npz).  The per-pose picture (argmin agreement, error deltas) goes to the parity report."""
+    PA-MPJPE within max(0.05 mm, a 95 % prediction interval from the REFERENCE's own runs of THIS capture on detections that
+    differ by one ulp) of the mean of those runs (tests/golden/<capture>_env*.npz; round 5).  The per-pose picture (argmin
+    agreement, error deltas) goes to the parity report."""
     import json
     import zedo_hip
     from zedo_hip.pipeline import Pipeline, ZeDOConfig
@@ -370,32 +381,32 @@ def test_fused_driver_at_baseline_size_matches_reference(weights0, golden, name)
     with open("gpurun_out/parity_report.jsonl", "a") as f:
         f.write(json.dumps(rep) + "\n")
     print(json.dumps(rep))
-    # Bar of BASELINE.json: both dataset means within 0.05 mm of the reference - or, where the REFERENCE's own fp32 run does
-    # not reproduce itself that closely, within its self-envelope: tests/golden/driver_pw3d_full_env{1..4}.npz are the
-    # reference's full run (IPO + 1000 steps + selection, 2.4 CPU-hours each) on four copies of draw A's detections moved by
-    # -1/0/+1 ulp; envelope = the largest difference between two of its five runs (all three configs[2] draws have the
-    # same shape and settings).  configs[1] (H36M settings, one hypothesis) meets 0.05 mm outright and has no envelope.
-    # The round-3 clause "|mean delta| <= 3 standard errors" is gone; the distributional side is tests/test_ensemble_gpu.py.
-    envelope = {"p1": 0.0, "p2": 0.0}
-    if not h36m:
-        def runs_of(tag):
-            r, k = [golden(tag)], 1
-            while os.path.exists(os.path.join(ROOT, "tests", "golden", f"{tag}_env{k}.npz")):
-                r.append(golden(f"{tag}_env{k}"))
-                k += 1
-            return r
-        spread = lambda rs, key: (max(float(r[key]) for r in rs) - min(float(r[key]) for r in rs)) * 1e3
-        # the capture's own members where it has at least two of them, and never less than draw A's five-run envelope: all
-        # configs[2] draws share shape and settings
-        own, base = runs_of(name), runs_of("driver_pw3d_full")
-        assert len(base) >= 5, "tests/golden/driver_pw3d_full_env{1..4}.npz are missing"
-        envelope = {"p1": max(spread(base, "mpjpe"), spread(own, "mpjpe") if len(own) >= 3 else 0.0),
-                    "p2": max(spread(base, "pa_mpjpe"), spread(own, "pa_mpjpe") if len(own) >= 3 else 0.0)}
+    # Bar of BASELINE.json: both dataset means within 0.05 mm of the reference - or, where the REFERENCE's own fp32 run does not
+    # reproduce itself that closely, inside the reference's own scatter ON THIS DRAW: tests/golden/<capture>_env{k}.npz are the
+    # reference's full run (IPO + 1000 steps + selection) on copies of this capture's detections moved by -1/0/+1 ulp.  Round 5:
+    # the bound is a 95 % t PREDICTION INTERVAL for one more run, from this capture's own K runs (mean m, sd s):
+    # |x - m| <= t(0.975, K-1) s sqrt(1 + 1/K) - not the max-min of five numbers, and never another draw's envelope (round 4
+    # passed draw b on draw A's 0.436 mm).  Both protocols, every capture, configs[1] included (its PA-MPJPE scatters by 0.022 mm).
+    # The interval cannot go below the bar itself.  The distributional side is tests/test_ensemble_gpu.py.
+    from scipy import stats
+    runs, k = [g], 1
+    while os.path.exists(os.path.join(ROOT, "tests", "golden", f"{name}_env{k}.npz")):
+        runs.append(golden(f"{name}_env{k}"))
+        k += 1
+    K = len(runs)
+    assert K >= 5, f"tests/golden/{name}_env*.npz: at least four ulp-perturbed reference runs are needed"
+    bound, centre = {}, {}
+    for key, hip in (("mpjpe", p1), ("pa_mpjpe", p2)):
+        v = np.array([float(r[key]) for r in runs]) * 1e3
+        centre[key] = float(v.mean())
+        bound[key] = max(0.05, float(stats.t.ppf(0.975, K - 1) * v.std(ddof=1) * np.sqrt(1 + 1 / K)))
+        rep[f"d_{key}_vs_reference_mean_mm"] = hip * 1e3 - centre[key]
     with open("gpurun_out/parity_report.jsonl", "a") as f:
-        f.write(json.dumps({"test": name + "_envelope", "d_mpjpe_mm": rep["d_mpjpe_mm"], "d_pa_mpjpe_mm": rep["d_pa_mpjpe_mm"],
-                            "reference_self_envelope_mm": envelope}) + "\n")
-    assert rep["d_pa_mpjpe_mm"] <= 0.05, rep["d_pa_mpjpe_mm"]                      # PA-MPJPE: the bar, outright, every capture
-    assert rep["d_mpjpe_mm"] <= max(0.05, envelope["p1"]), (rep["d_mpjpe_mm"], envelope)
+        f.write(json.dumps({"test": name + "_prediction_interval", "reference_runs": K, "reference_mean_mm": centre, "half_width_mm": bound,
+                            "d_mpjpe_mm": rep["d_mpjpe_vs_reference_mean_mm"], "d_pa_mpjpe_mm": rep["d_pa_mpjpe_vs_reference_mean_mm"],
+                            "d_vs_unperturbed_run_mm": [rep["d_mpjpe_mm"], rep["d_pa_mpjpe_mm"]]}) + "\n")
+    assert abs(rep["d_pa_mpjpe_vs_reference_mean_mm"]) <= bound["pa_mpjpe"], (rep["d_pa_mpjpe_vs_reference_mean_mm"], bound)
+    assert abs(rep["d_mpjpe_vs_reference_mean_mm"]) <= bound["mpjpe"], (rep["d_mpjpe_vs_reference_mean_mm"], bound)
     # per pose, against the fp64 arbiter: no farther from exact arithmetic than the reference's own fp32 run (x1.5)
     if arb is not None:
         for key in ("p1", "p2"):

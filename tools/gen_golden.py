@@ -1052,14 +1052,15 @@ def gen_driver_ipo_pins():
 
 
 
-def _driver_oil_f64_from_pins(tag, N, H, S, seed_pose, seed_cl, conf_mode, cache_dir):
+def _driver_oil_f64_from_pins(tag, N, H, S, seed_pose, seed_cl, conf_mode, cache_dir, h36m=False):
     """Arbiter of parity stage (A): the reference's OIL loop (opt_main.py:197-222) re-run in float64 FROM THE SAME
     (R, T) the reference's fp32 run produced (tests/golden/<tag>_ipo.npz) - i.e. exact arithmetic on the inputs the fp32
     reference run and the HIP loop both start from.  How far the reference's own fp32 loop drifts from it is the
-    yardstick for the HIP loop's drift.  3DPW metric (plain mean).  ~80 CPU-minutes for configs[2]; resumable."""
+    yardstick for the HIP loop's drift.  Per-(pose, hypothesis) errors against the root-centred ground truth (3DPW: float32
+    metres; h36m=True: float64 millimetres centred the way h36m.py:400-401 does).  ~80 CPU-minutes for configs[2]; resumable."""
     w = syn.make_weights(seed=0)
     m = ref_model(w, torch.float64)
-    d = syn.make_poses(N, seed=seed_pose, conf_mode=conf_mode)
+    d = syn.make_poses(N, seed=seed_pose, conf_mode=conf_mode, dtype3d=np.float64 if h36m else np.float32)
     cl = syn.make_clusters(H, seed=seed_cl)
     gt_2d, K = d["db_2d"], d["camera_param"]
     pin = np.load(os.path.join(OUT, tag + "_ipo.npz"))
@@ -1084,7 +1085,11 @@ def _driver_oil_f64_from_pins(tag, N, H, S, seed_pose, seed_cl, conf_mode, cache
             print(f"  {tag} oil64: hypothesis {sid + 1}/{H} in {time.time() - t0:.0f} s", flush=True)
         res_all.append(res)
     br = np.swapaxes(np.array(res_all), 0, 1)
-    gtc = (d["db_3d"] - d["db_3d"][:, 0:1]).astype(np.float64)
+    if h36m:
+        mm = d["db_3d"] * 1000.0
+        gtc = (mm - mm[:, 0:1]) / 1000.0
+    else:
+        gtc = (d["db_3d"] - d["db_3d"][:, 0:1]).astype(np.float64)
     e1 = np.linalg.norm(br - gtc[:, None], axis=-1).mean(-1)
     e2 = np.zeros((N, H))
     for n in range(N):
@@ -1094,6 +1099,10 @@ def _driver_oil_f64_from_pins(tag, N, H, S, seed_pose, seed_cl, conf_mode, cache
     save(tag + "_oil64", N=np.int64(N), H=np.int64(H), S=np.int64(S), err_p1=e1.astype(np.float32), err_p2=e2.astype(np.float32),
          best_p1=e1.min(1), best_p2=e2.min(1), argmin_p1=e1.argmin(1).astype(np.int32), argmin_p2=e2.argmin(1).astype(np.int32),
          mpjpe=np.float64(e1.min(1).mean()), pa_mpjpe=np.float64(e2.min(1).mean()), inputs_sha=pin["inputs_sha"])
+
+
+def gen_driver_h36m_full_oil64():
+    _driver_oil_f64_from_pins("driver_h36m_full", 886, 1, 1000, 101, 17, "uniform", CACHE, h36m=True)
 
 
 def gen_driver_pw3d_full_oil64():
@@ -1115,10 +1124,10 @@ GENS = dict(model=gen_model, weights_alt=gen_weights_alt, pc_step=gen_pc_step, r
             driver_h36m_full=gen_driver_h36m_full, driver_pw3d_full=gen_driver_pw3d_full,
             driver_h36m_full_f64=gen_driver_h36m_full_f64, driver_pw3d_full_f64=gen_driver_pw3d_full_f64,
             driver_pw3d_full_b=gen_driver_pw3d_full_b, driver_pw3d_full_c=gen_driver_pw3d_full_c,
-            driver_ipo_pins=gen_driver_ipo_pins, driver_pw3d_full_oil64=gen_driver_pw3d_full_oil64, driver_pw3d_full_b_oil64=gen_driver_pw3d_full_b_oil64,
+            driver_ipo_pins=gen_driver_ipo_pins, driver_h36m_full_oil64=gen_driver_h36m_full_oil64, driver_pw3d_full_oil64=gen_driver_pw3d_full_oil64, driver_pw3d_full_b_oil64=gen_driver_pw3d_full_b_oil64,
             driver_pw3d_full_c_oil64=gen_driver_pw3d_full_c_oil64, driver_pw3d_full_env=gen_driver_pw3d_full_env,
             driver_pw3d_ipoens=gen_driver_pw3d_ipoens, driver_pw3d_full_tied=gen_driver_pw3d_full_tied, driver_full_env=gen_driver_full_env, driver_h36m_full_env=gen_driver_h36m_full_env)
-SLOW = {"driver_pw3d_full", "driver_pw3d_full_f64", "driver_pw3d_full_b", "driver_pw3d_full_c", "driver_ipo_pins", "driver_pw3d_full_oil64", "driver_pw3d_full_b_oil64",
+SLOW = {"driver_h36m_full_oil64", "driver_pw3d_full", "driver_pw3d_full_f64", "driver_pw3d_full_b", "driver_pw3d_full_c", "driver_ipo_pins", "driver_pw3d_full_oil64", "driver_pw3d_full_b_oil64",
         "driver_pw3d_full_c_oil64", "driver_pw3d_full_env", "driver_pw3d_ipoens", "driver_pw3d_full_tied", "driver_full_env", "driver_h36m_full_env"}     # only with --only
 
 if __name__ == "__main__":

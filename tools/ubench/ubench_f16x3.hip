@@ -33,6 +33,7 @@ struct Args {
     float unscale;        // 2^-wshift
     long long *clk;       // {shader cycles, 100 MHz ticks} of workgroup 0
     int stagger;          // experiment: first-round workgroups of CU slot s start s * stagger x 8128 cycles late
+    int kmajor;           // round 5: operands stored [k/16][row][64 bytes] (the rows of a k block contiguous) instead of [row][k/16][64 bytes]
 };
 
 __device__ __forceinline__ void dma16(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
@@ -77,17 +78,20 @@ __global__ __launch_bounds__(WM *WN * 64, WPE) void hf_kernel(Args a) {
     // every 16-lane group of a ds_read_b128 (rows li of {0-3,12-15,20-27} / {4-11,16-19,28-31}) then hits 16 distinct slots
     auto swz = [](int row) { return CPR == 4 ? ((row >> 2) & 3) : (row & 7); };
     unsigned woff[IA], xoff[IB];
+    const size_t rs_ = a.kmajor ? 64 : rstride;              // bytes between the rows of one k block
 #pragma unroll
-    for (int p = 0; p < IA; ++p) { const int g = (wid * IA + p) * 64 + lane; const int r_ = g / CPR, c_ = (g % CPR) ^ swz(r_); woff[p] = (unsigned)(r_ * rstride + c_ * 16); }
+    for (int p = 0; p < IA; ++p) { const int g = (wid * IA + p) * 64 + lane; const int r_ = g / CPR, c_ = (g % CPR) ^ swz(r_); woff[p] = (unsigned)(r_ * rs_ + c_ * 16); }
 #pragma unroll
-    for (int p = 0; p < IB; ++p) { const int g = (wid * IB + p) * 64 + lane; const int r_ = g / CPR, c_ = (g % CPR) ^ swz(r_); xoff[p] = (unsigned)(r_ * rstride + c_ * 16); }
+    for (int p = 0; p < IB; ++p) { const int g = (wid * IB + p) * 64 + lane; const int r_ = g / CPR, c_ = (g % CPR) ^ swz(r_); xoff[p] = (unsigned)(r_ * rs_ + c_ * 16); }
+    const char *Wk0 = reinterpret_cast<const char *>(a.W2) + (size_t)n0 * 64, *Xk0 = reinterpret_cast<const char *>(a.X2) + (size_t)m0 * 64;
+    const size_t wks = (size_t)a.N * 64, xks = (size_t)a.M * 64;      // k-major: bytes between k blocks
     auto dma_one = [&](int st, int slot, int p) {     // DMA instruction p of a stage: W rows first, then X rows
-        const char *wk = Wbase + (size_t)st * RB, *xk = Xbase + (size_t)st * RB;
+        const char *wk = a.kmajor ? Wk0 + (size_t)st * wks : Wbase + (size_t)st * RB, *xk = a.kmajor ? Xk0 + (size_t)st * xks : Xbase + (size_t)st * RB;
         if (p < IA) dma16(wk, woff[p], lds0 + slot * SLOT + (wid * IA + p) * 1024);
         else dma16(xk, xoff[p - IA], lds0 + slot * SLOT + BN * RB + (wid * IB + (p - IA)) * 1024);
     };
     auto dma = [&](int st, int slot) {
-        const char *wk = Wbase + (size_t)st * RB, *xk = Xbase + (size_t)st * RB;
+        const char *wk = a.kmajor ? Wk0 + (size_t)st * wks : Wbase + (size_t)st * RB, *xk = a.kmajor ? Xk0 + (size_t)st * xks : Xbase + (size_t)st * RB;
 #pragma unroll
         for (int p = 0; p < IA; ++p) dma16(wk, woff[p], lds0 + slot * SLOT + (wid * IA + p) * 1024);
 #pragma unroll
@@ -526,10 +530,19 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dg, hg.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dbe, hbe.data(), N * 4, hipMemcpyHostToDevice));
     long long *dclk; CK(hipMalloc(&dclk, 16)); CK(hipMemset(dclk, 0, 16)); a.clk = dclk;
+    // k-block-major copies of both operands: [k/16][row][2][16]
+    std::vector<uint16_t> x2k(x2.size()), w2k(w2.size());
+    for (int r = 0; r < M; ++r) for (int kb = 0; kb < K / 16; ++kb) memcpy(&x2k[((size_t)kb * M + r) * 32], &x2[((size_t)r * (K / 16) + kb) * 32], 64);
+    for (int r = 0; r < N; ++r) for (int kb = 0; kb < K / 16; ++kb) memcpy(&w2k[((size_t)kb * N + r) * 32], &w2[((size_t)r * (K / 16) + kb) * 32], 64);
+    uint16_t *dxk, *dwk;
+    CK(hipMalloc(&dxk, x2k.size() * 2)); CK(hipMalloc(&dwk, w2k.size() * 2));
+    CK(hipMemcpy(dxk, x2k.data(), x2k.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dwk, w2k.data(), w2k.size() * 2, hipMemcpyHostToDevice));
     a.X2 = dx; a.W2 = dw; a.bias = db; a.gamma = dg; a.beta = dbe; a.out = dy; a.M = M; a.N = N; a.K = K; a.unscale = 1.0f / wscale;
     //    BM   BN  WM WN NBUF NODMA WPE KPS      NODMA bits: 1 no in-loop DMA, 2 no in-loop LDS reads, 4 no in-loop barrier
     const int only = argc > 3 ? atoi(argv[3]) : -1;
     a.stagger = argc > 4 ? atoi(argv[4]) : 0;
+    a.kmajor = argc > 5 ? atoi(argv[5]) : 0;
+    if (a.kmajor) { a.X2 = dxk; a.W2 = dwk; printf("operands k-block-major ([k/16][row][64 B])\n"); }
     int v = 0;
 #define RUN(NAME, ...) { if (only < 0 || only == v) run<__VA_ARGS__>(NAME, a, rows, cref); ++v; }
     RUN("128x128 4w ring2 k16 lb3", 128, 128, 2, 2, 2, 0, 3, 1)

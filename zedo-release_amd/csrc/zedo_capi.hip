@@ -339,9 +339,9 @@ extern "C" int zedo_weights_set_math(zedo_weights_t *w, int mode, void *stream) 
             const int shift = wm > 0.f ? 14 - ex : 0;
             w->unscale[l] = std::ldexp(1.0f, -shift);
             const float sc = std::ldexp(1.0f, shift);
-            if (l < 4) e = launch_split_planes(w->W_hid[l], HID, HID, HID, sc, w->d_W16 + (size_t)l * per, st);
-            else if (l == 4) e = launch_split_planes(w->W_pre, HID, XLD, XLD, sc, w->d_W16 + 4 * per, st);
-            else e = launch_split_planes(w->W_post, XLD, HID, HID, sc, w->d_W16 + 4 * per + (size_t)HID * XLD * 2, st);
+            if (l < 4) e = launch_split_planes(w->W_hid[l], HID, HID, HID, sc, w->d_W16 + (size_t)l * per, HID, st);
+            else if (l == 4) e = launch_split_planes(w->W_pre, HID, XLD, XLD, sc, w->d_W16 + 4 * per, HID, st);
+            else e = launch_split_planes(w->W_post, XLD, HID, HID, sc, w->d_W16 + 4 * per + (size_t)HID * XLD * 2, XLD, st);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { (void)hipFree(w->d_W16); w->d_W16 = nullptr; return (int)e; }
@@ -429,7 +429,9 @@ extern "C" int zedo_schedule_read(const zedo_schedule_t *s, float *h_tbias, floa
     return ZEDO_OK;
 }
 
-static inline size_t ws_rows(int B) { return (size_t)round_up((int)std::min((size_t)B, chunk_rows_cap()), BATCH_PAD); }
+// rows of the workspace buffers: the chunk's rows rounded up to 128 (the 128-row tiles of the split-fp16 ping-pong kernel read - and write -
+// whole tiles; the rows behind the batch's own padded rows are never used as results)
+static inline size_t ws_rows(int B) { return (size_t)round_up((int)std::min((size_t)B, chunk_rows_cap()), 2 * BATCH_PAD); }
 
 extern "C" size_t zedo_workspace_bytes(int B) {
     if (B < 1) return 0;
@@ -474,14 +476,14 @@ struct NextReproj {          // reprojection of the next loop iteration, fused i
 
 // ZEDO_MATH_F16X3: the same six layers on the fp16 matrix pipe (zedo_gemm16.hip).  h / h1 hold the activations as split-fp16
 // planes (the same 4 bytes per element); the pose state xpad, the time-bias rows and the SDE / reprojection epilogue stay fp32.
-static hipError_t mlp_layers_f16(const zedo_weights *w, const float *tb, float *xpad, float *h, float *h1, int Bp, bool sde,
+static hipError_t mlp_layers_f16(const zedo_weights *w, const float *tb, float *xpad, float *h, float *h1, int Bp, int ld, bool sde,
                                  float sa, float sc, float *eps_out, hipStream_t st, const NextReproj &nr) {
     const size_t per = (size_t)HID * HID * 2;                 // uint16 per hidden weight matrix
     const uint16_t *W_pre16 = w->d_W16 + 4 * per, *W_post16 = W_pre16 + (size_t)HID * XLD * 2;
     hipError_t e;
     {   // pre_dense + pre_gnorm + SiLU: X = the fp32 pose rows, split by the kernel
         Layer16Args b{};
-        b.K = XLD; b.N = HID; b.Mp = Bp; b.Xf32 = xpad; b.W = W_pre16; b.unscale = w->unscale[4];
+        b.K = XLD; b.N = HID; b.Mp = Bp; b.ldo = ld; b.Xf32 = xpad; b.W = W_pre16; b.unscale = w->unscale[4];
         b.bias = tb; b.gamma = w->gamma[0]; b.beta = w->beta[0]; b.out = h; b.out_f32 = 0;
         ProfScope ps(ZEDO_PROF_PRE, st);
         e = launch_layer16(b, EPI_GN_SILU, st);
@@ -489,7 +491,7 @@ static hipError_t mlp_layers_f16(const zedo_weights *w, const float *tb, float *
     for (int blk = 0; blk < 2 && e == hipSuccess; ++blk) {
         const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
         Layer16Args b{};
-        b.K = HID; b.N = HID; b.Mp = Bp; b.out_f32 = 0;
+        b.K = HID; b.N = HID; b.Mp = Bp; b.ldx = b.ldo = ld; b.out_f32 = 0;
         b.X = reinterpret_cast<const uint16_t *>(h); b.W = w->d_W16 + (size_t)(l1 - 1) * per; b.unscale = w->unscale[l1 - 1];
         b.bias = tb + (size_t)l1 * HID; b.gamma = w->gamma[l1]; b.beta = w->beta[l1]; b.out = h1;
         { ProfScope ps(ZEDO_PROF_HIDDEN, st); b.clk = ps.clk; e = launch_layer16(b, EPI_GN_SILU, st); b.clk = nullptr; }
@@ -502,7 +504,7 @@ static hipError_t mlp_layers_f16(const zedo_weights *w, const float *tb, float *
     }
     if (e != hipSuccess) return e;
     Layer16Args b{};
-    b.K = HID; b.N = XLD; b.Mp = Bp; b.X = reinterpret_cast<const uint16_t *>(h);
+    b.K = HID; b.N = XLD; b.Mp = Bp; b.ldx = ld; b.X = reinterpret_cast<const uint16_t *>(h);
     b.W = W_post16; b.unscale = w->unscale[5]; b.bias = w->b_post;
     ProfScope ps(ZEDO_PROF_POST, st);
     if (sde) {
@@ -514,9 +516,10 @@ static hipError_t mlp_layers_f16(const zedo_weights *w, const float *tb, float *
     return launch_layer16(b, EPI_BIAS, st);
 }
 
-static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad, float *h, float *h1, int Bp, bool sde,
+// ld: rows of the workspace buffers h / h1 (>= Bp): the split-fp16 mode stores its activations k-block-major, [channel / 16][ld][64 bytes]
+static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad, float *h, float *h1, int Bp, int ld, bool sde,
                              float sa, float sc, float *eps_out, hipStream_t st, const NextReproj &nr = NextReproj()) {
-    if (w->math == ZEDO_MATH_F16X3) return mlp_layers_f16(w, tb, xpad, h, h1, Bp, sde, sa, sc, eps_out, st, nr);
+    if (w->math == ZEDO_MATH_F16X3) return mlp_layers_f16(w, tb, xpad, h, h1, Bp, ld, sde, sa, sc, eps_out, st, nr);
     LayerArgs a{};
     a.Mp = Bp;
     // pre_dense + pre_gnorm + SiLU
@@ -568,11 +571,11 @@ static int step_common(const zedo_weights_t *w, const zedo_schedule_t *s, int st
         Ws k = carve(ws, B);
         HIPCHK(launch_pack_rows(d_x_in + r0 * w->J3, k.xpad, Bc, Bp, w->J3, st));
         if (sde) {
-            HIPCHK(mlp_layers(w, tb, k.xpad, k.h, k.h1, Bp, true, s->a[step], s->c[step], nullptr, st));
+            HIPCHK(mlp_layers(w, tb, k.xpad, k.h, k.h1, Bp, (int)k.rows, true, s->a[step], s->c[step], nullptr, st));
             HIPCHK(launch_unpack_rows(k.xpad, d_out + r0 * w->J3, Bc, w->J3, st));
         } else {
             // eps lands in h1's first XLD columns region: reuse h1 as [Bp][XLD]
-            HIPCHK(mlp_layers(w, tb, k.xpad, k.h, k.h1, Bp, false, 0.f, 0.f, k.h1, st));
+            HIPCHK(mlp_layers(w, tb, k.xpad, k.h, k.h1, Bp, (int)k.rows, false, 0.f, 0.f, k.h1, st));
             HIPCHK(launch_unpack_rows(k.h1, d_out + r0 * w->J3, Bc, w->J3, st));
         }
     }
@@ -620,7 +623,7 @@ extern "C" int zedo_oil_run(const zedo_weights_t *w, const zedo_schedule_t *s, f
                 nr.row0 = row_offset + (long long)r0;
             }
             // sampling_fn(...) (run/opt_main.py:210-218) -> x = a_i x + c_i eps(x, t_i)  [+ the next correction]
-            HIPCHK(mlp_layers(w, s->d_tbias + (size_t)i * NLAYER * HID, k.xpad, k.h, k.h1, Bp, true, s->a[i], s->c[i],
+            HIPCHK(mlp_layers(w, s->d_tbias + (size_t)i * NLAYER * HID, k.xpad, k.h, k.h1, Bp, (int)k.rows, true, s->a[i], s->c[i],
                               nullptr, st, nr));
         }
         HIPCHK(launch_unpack_rows(k.xpad, d_x + r0 * w->J3, Bc, w->J3, st));

@@ -30,13 +30,16 @@
 #include "zedo_internal.h"
 #include "zedo_tile.h"
 
+#include <algorithm>
 #include <atomic>
+#include <cstdlib>
+#include <type_traits>
 
 namespace zedo {
 
-// fp32 [rows][cols] (row stride ld) * scale -> planes
+// fp32 [rows][cols] (row stride ld) * scale -> planes [cols/16][ldr][2][16] (k-block-major, zedo_tile.h)
 __global__ void split_planes_kernel(const float *__restrict__ src, int rows, int cols, int ld, float scale,
-                                    uint16_t *__restrict__ dst) {
+                                    uint16_t *__restrict__ dst, int ldr) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread = 8 consecutive columns
     const int per_row = cols / 8;
     if (i >= (size_t)rows * per_row) return;
@@ -47,15 +50,15 @@ __global__ void split_planes_kernel(const float *__restrict__ src, int rows, int
     for (int e = 0; e < 4; ++e) { v0[e] *= scale; v1[e] *= scale; }
     f16x8 h, l;
     split_f16x8(v0, v1, h, l);
-    char *d = reinterpret_cast<char *>(dst) + (size_t)r * cols * 4 + (c >> 4) * 64 + ((c >> 3) & 1) * 16;
+    char *d = reinterpret_cast<char *>(dst) + ((size_t)(c >> 4) * ldr + r) * 64 + ((c >> 3) & 1) * 16;
     *reinterpret_cast<f16x8 *>(d) = h;
     *reinterpret_cast<f16x8 *>(d + 32) = l;
 }
 
-hipError_t launch_split_planes(const float *src, int rows, int cols, int ld, float scale, uint16_t *dst, hipStream_t st) {
-    if (cols % 16 || ld % 4) return hipErrorInvalidValue;
+hipError_t launch_split_planes(const float *src, int rows, int cols, int ld, float scale, uint16_t *dst, int ldr, hipStream_t st) {
+    if (cols % 16 || ld % 4 || ldr < rows) return hipErrorInvalidValue;
     const size_t n = (size_t)rows * (cols / 8);
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, rows, cols, ld, scale, dst);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, rows, cols, ld, scale, dst, ldr);
     return hipGetLastError();
 }
 
@@ -92,20 +95,22 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN, li = lane & 31, kh = lane >> 5;
-    const size_t xstride = (size_t)a.K * 4;                           // bytes per operand row (planes: 4 bytes per element)
-    const char *Wbase = reinterpret_cast<const char *>(a.W) + (size_t)n0 * xstride;
-    const char *Xbase = reinterpret_cast<const char *>(a.X) + (size_t)m0 * xstride;
+    // planes are k-block-major: block kb of row r at ((kb * ld + r) * 64 bytes: the rows of a block are contiguous, a 1-KB DMA
+    // instruction reads 1 KB of memory (16 rows x 64 bytes; round 5 - with [row][k/16] rows 4 KB apart the same stream ran at 0.6x)
+    const size_t wkb = (size_t)a.N * RB, xkb = (size_t)a.ldx * RB;   // bytes between k blocks of W / X
+    const char *Wbase = reinterpret_cast<const char *>(a.W) + (size_t)n0 * RB;
+    const char *Xbase = reinterpret_cast<const char *>(a.X) + (size_t)m0 * RB;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem16;
 
     // DMA instruction p of this wave moves the 16-byte chunks g = (wid * I + p) * 64 + lane of the tile's block: LDS row
     // g / 4, position g % 4, which holds source chunk (g % 4) ^ swz(row)
     unsigned woff[IA], xoff[IB];
 #pragma unroll
-    for (int p = 0; p < IA; ++p) { const int g = (wid * IA + p) * 64 + lane, r = g / CPR; woff[p] = (unsigned)(r * xstride + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
+    for (int p = 0; p < IA; ++p) { const int g = (wid * IA + p) * 64 + lane, r = g / CPR; woff[p] = (unsigned)(r * RB + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
 #pragma unroll
-    for (int p = 0; p < IB; ++p) { const int g = (wid * IB + p) * 64 + lane, r = g / CPR; xoff[p] = (unsigned)(r * xstride + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
+    for (int p = 0; p < IB; ++p) { const int g = (wid * IB + p) * 64 + lane, r = g / CPR; xoff[p] = (unsigned)(r * RB + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
     auto dma = [&](int kb, int slot) {
-        const char *wk = Wbase + (size_t)kb * RB, *xk = Xbase + (size_t)kb * RB;
+        const char *wk = Wbase + (size_t)kb * wkb, *xk = Xbase + (size_t)kb * xkb;
 #pragma unroll
         for (int p = 0; p < IA; ++p) dma16(wk, woff[p], lds0 + slot * SLOT + (wid * IA + p) * 1024);
         if constexpr (!XF32) {
@@ -219,8 +224,12 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     if constexpr (GN) {
         constexpr int CG = BN / 16;              // 16-channel groups per stage row
         float *S = reinterpret_cast<float *>(smem16);
-        char *obase = reinterpret_cast<char *>(a.out) + (size_t)m0 * a.N * 4 + (size_t)n0 * 4;
-        const char *rbase = reinterpret_cast<const char *>(a.res) + (size_t)m0 * a.N * 4 + (size_t)n0 * 4;
+        // planes out (and residual): 16-channel group cg of row r at ((n0 / 16 + cg) * ldo + m0 + r) * 64 bytes; fp32 out: row-major [Mp][N]
+        const bool pl_out = !a.out_f32;
+        const size_t orow = pl_out ? 64 : (size_t)a.N * 4, ogrp = pl_out ? (size_t)a.ldo * 64 : 64;
+        char *obase = reinterpret_cast<char *>(a.out) + (pl_out ? ((size_t)(n0 >> 4) * a.ldo + m0) * 64 : (size_t)m0 * a.N * 4 + (size_t)n0 * 4);
+        const char *rbase = reinterpret_cast<const char *>(a.res) + ((size_t)(n0 >> 4) * a.ldo + m0) * 64;
+        const size_t rgrp = (size_t)a.ldo * 64;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
 #pragma unroll
@@ -257,7 +266,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
                 for (int it = 0; it < ITEMS; ++it) {
                     const int qi = it * NT + tid, sr = qi / CG, cg = qi % CG;
                     const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
-                    const unsigned off = (unsigned)grow * (unsigned)a.N * 4u + (unsigned)cg * 64u;
+                    const size_t off = (size_t)grow * 64 + (size_t)cg * rgrp;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) rres[it][q] = *reinterpret_cast<const f16x8 *>(rbase + off + 16 * q);
                 }
@@ -266,7 +275,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
             for (int it = 0; it < ITEMS; ++it) {
                 const int qi = it * NT + tid, sr = qi / CG, cg = qi % CG;
                 const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
-                const unsigned off = (unsigned)grow * (unsigned)a.N * 4u + (unsigned)cg * 64u;
+                const size_t off = (size_t)grow * orow + (size_t)cg * ogrp;
                 f32x4 v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4 *>(S + sr * BN + (((cg * 4 + q) ^ (sr & 7)) << 2));
@@ -439,6 +448,10 @@ __global__ __launch_bounds__(256, 4) void layer16_small_kernel(Layer16Args a) {
     layer16_body<64, 64, 2, 2, EPI, 4, 0>(a, blockIdx.x, gridDim.x);
 }
 
+#ifdef ZEDO_UBENCH      // round 5's tile ping-pong experiment (not part of the library): see the file
+#include "../../tools/ubench/zedo_gemm16_tp.inc"
+#endif
+
 constexpr int MAX_DEVICES16 = MAX_DEVICES;      // per-device launch state: allow_lds / num_cus of zedo_internal.h
 
 template <class K>
@@ -466,15 +479,16 @@ static hipError_t launch_pair16(const Layer16Args &big, const Layer16Args &small
 
 static Layer16Args rows_of16(const Layer16Args &a, int row0, int rows) {
     Layer16Args b = a;
-    b.X = a.X + (size_t)row0 * a.K * 2;            // uint16 units: 4 bytes per element
-    b.out = reinterpret_cast<char *>(a.out) + (size_t)row0 * a.N * 4;
-    if (a.res) b.res = a.res + (size_t)row0 * a.N * 2;
+    b.X = a.X + (size_t)row0 * 32;                 // uint16 units: a row of a k block is 64 bytes; ldx / ldo stay
+    b.out = reinterpret_cast<char *>(a.out) + (a.out_f32 ? (size_t)row0 * a.N * 4 : (size_t)row0 * 64);
+    if (a.res) b.res = a.res + (size_t)row0 * 32;
     b.Mp = rows;
     return b;
 }
 
 hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st) {
     if (a.Mp <= 0 || a.Mp % 64 || a.K % 64 || !a.W) return hipErrorInvalidValue;
+    if ((a.X && a.ldx < a.Mp) || (a.out && !a.out_f32 && a.N != XLD && a.ldo < a.Mp)) return hipErrorInvalidValue;   // planes operands carry their row count
     if (a.Xf32) {               // pre_dense
         if (a.K != XLD || a.N % 128 || epilogue != EPI_GN_SILU || !a.out) return hipErrorInvalidValue;
         static std::atomic<bool> done[MAX_DEVICES16];

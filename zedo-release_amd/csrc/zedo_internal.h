@@ -94,12 +94,14 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st);
 // One hidden layer on the fp16 matrix pipe (zedo_gemm16.hip): out = epilogue(X . W^T * unscale + bias), X and W in the
 // split-fp16 planes format, three 32x32x16 fp16 MFMAs (hl, lh, hh) per 16-k block, fp32 accumulation.
 struct Layer16Args {
-    const uint16_t *X;      // planes [Mp][K/16][2][16]
-    const uint16_t *W;      // planes [N][K/16][2][16] of W * 2^wshift
+    // planes are K-BLOCK-MAJOR (zedo_tile.h): [K/16][ld rows][2 planes][16], i.e. the 64 bytes of (block kb, row r) at (kb * ld + r) * 64
+    const uint16_t *X;      // planes [K/16][ldx][2][16], rows [0, Mp) used
+    int ldx, ldo;           // rows per k block of the X buffer / per 16-channel group of the out and res buffers (>= Mp; the workspace's row count)
+    const uint16_t *W;      // planes [K/16][N][2][16] of W * 2^wshift
     const float *bias, *gamma, *beta;   // [N]
     float unscale;          // 2^-wshift (exact)
-    const uint16_t *res;    // EPI_GN_SILU_RES: residual planes [Mp][N/16][2][16]; may be the output buffer (in place)
-    void *out;              // planes [Mp][N/16][2][16] (out_f32 == 0) or fp32 [Mp][N] (out_f32 != 0): the same 4 N bytes per row
+    const uint16_t *res;    // EPI_GN_SILU_RES: residual planes [N/16][ldo][2][16]; may be the output buffer (in place)
+    void *out;              // planes [N/16][ldo][2][16] (out_f32 == 0) or fp32 [Mp][N] (out_f32 != 0): the same 4 N bytes per row
     int out_f32;
     int K, N, Mp;           // K % 64 == 0, N % 128 == 0 (or N == 64: post_dense), Mp % 64 == 0
     long long *clk;         // diagnostic (may be null), as in LayerArgs
@@ -115,8 +117,8 @@ struct Layer16Args {
     long long rp_row0;
 };
 hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st);
-// fp32 [rows][cols] (row stride ld floats) * scale -> planes [rows][cols/16][2][16]; cols % 16 == 0
-hipError_t launch_split_planes(const float *src, int rows, int cols, int ld, float scale, uint16_t *dst, hipStream_t st);
+// fp32 [rows][cols] (row stride ld floats) * scale -> planes [cols/16][ldr][2][16] (k-block-major; ldr >= rows); cols % 16 == 0
+hipError_t launch_split_planes(const float *src, int rows, int cols, int ld, float scale, uint16_t *dst, int ldr, hipStream_t st);
 hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStream_t st);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
