@@ -79,7 +79,9 @@ void zedo_weights_destroy(zedo_weights_t *w);
  *   last bits, like any two fp32 implementations of the network do; the geometry kernels (reprojection, IPO, metric) and the
  *   fp32 pose state are unchanged.  Activations are stored as unscaled fp16 pieces: the call returns ZEDO_E_BADARG for a
  *   network whose GroupNorm parameters could produce |activation| >= 32768 (bound: sum over the residual path of
- *   max|gamma| sqrt(31) + max|beta|; trained checkpoints: O(10)) and for non-finite weights.
+ *   max|gamma| sqrt(31) + max|beta|; trained checkpoints: O(10)), for non-finite weights, and for a weight matrix with a non-zero
+ *   row whose largest entry is below 2^-8 of the matrix maximum (each matrix carries ONE scale: such a row would lose bits; DESIGN.md
+ *   section 3 has the bound).
  *   zedo_weights_set_math builds the split copy of the six weight matrices on first use and
  *   synchronises `stream`; the mode is a property of the handle and applies to every later call that takes it.
  */

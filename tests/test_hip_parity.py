@@ -690,6 +690,89 @@ def test_both_math_modes_are_fp32_accurate_against_the_fp64_oracle(zh, weights0)
         W.set_math("bf16")
 
 
+def _adversarial_weights(weights0, case):
+    """Networks built to sit on the weak spots of the split-fp16 arithmetic (include/zedo_hip.h ZEDO_MATH_F16X3)."""
+    w = {k: v.copy() for k, v in weights0.items()}
+    if case == "denormal_high_pieces":        # SiLU(-14) = -1.2e-5, SiLU(-9) = -1.1e-3: whole activations / their low pieces below fp16's 6.1e-5
+        w["pre_gnorm.bias"][:] = -14.0
+        w["b1_gnorm1.bias"][:] = -9.0
+    elif case == "denormal_low_pieces":       # activations ~ 5e-3: the high piece is normal, the low piece (x 2^-11) is not
+        w["pre_gnorm.weight"][:] = 0.01
+        w["pre_gnorm.bias"][:] = 0.0
+        w["b2_gnorm1.weight"][:] = 0.02
+    elif case == "scale_boundary":            # max |w| exactly on / one ulp below / one ulp above a power of two: the per-matrix shift changes by one
+        for name, target in (("b1_dense1.weight", np.float32(2.0 ** -5)), ("b1_dense2.weight", np.nextafter(np.float32(2.0 ** -5), np.float32(0))),
+                             ("b2_dense1.weight", np.nextafter(np.float32(2.0 ** -4), np.float32(1))), ("post_dense.weight", np.float32(2.0 ** -7))):
+            m = np.abs(w[name]).max()
+            w[name] = (w[name] * (target / m)).astype(np.float32)
+            i = np.unravel_index(np.abs(w[name]).argmax(), w[name].shape)
+            w[name][i] = np.sign(w[name][i]) * target
+            assert np.abs(w[name]).max() == target
+    elif case == "gamma_near_refusal":        # activation bound 32 237 + 11 + 11 < 32 768: accepted, and activations of ~2e4 really occur
+        w["pre_gnorm.weight"][:] = 5790.0
+    elif case == "range_2^30_in_a_group":     # pre-activations of one GroupNorm group spread over 2^30
+        b = w["pre_dense.bias"]
+        b[96:128] = np.where(np.arange(32) % 2 == 0, 2.0 ** 15, 2.0 ** -15).astype(np.float32)
+        b[512:544] = -(2.0 ** np.linspace(-15, 15, 32)).astype(np.float32)
+    elif case == "row_ratio_2^-7.9":          # half the rows of a matrix 2^-7.9 below its maximum: the smallest ratio the mode accepts
+        w["b2_dense1.weight"][::2] *= np.float32(2.0 ** -7.9)
+    else:
+        raise KeyError(case)
+    return w
+
+
+ADVERSARIAL = ["denormal_high_pieces", "denormal_low_pieces", "scale_boundary", "gamma_near_refusal", "range_2^30_in_a_group", "row_ratio_2^-7.9"]
+
+
+@pytest.mark.parametrize("case", ADVERSARIAL)
+def test_f16x3_on_adversarial_networks_against_the_fp64_oracle(zh, weights0, case):
+    """the split-fp16 mode on networks built to hurt it - fp16-denormal activations and low pieces, weight maxima
+    on the power-of-two boundary of the per-matrix scale, GroupNorm gains just under the refusal threshold, 2^30 of dynamic range
+    inside one GroupNorm group, rows at the smallest accepted ratio to their matrix maximum - against the oracle in float64, beside
+    the exact-fp32 mode on the same network.  Bound: per dense layer |dy| <= sum_k |w_k| (2^-22 |a_k| + 2^-24)
+    + 64 fp32 block additions, against 1024 chained fp32 roundings for the fma chain - so the mode must stay within 1.5 x the
+    exact-fp32 mode's distance from float64 (+ 3e-8 of the output scale for the absolute 2^-24 term), on every case."""
+    import zedo_oracle as O
+    w = _adversarial_weights(weights0, case)
+    g = np.random.Generator(np.random.Philox(key=[47, 3]))
+    x = (0.3 * g.standard_normal((1500, 17, 3))).astype(np.float32)
+    ts = np.array([0.1, 0.02], np.float32)
+    w64 = O.cast_weights(w, np.float64)
+    W = zh.Weights(w, math="f32")
+    s = zh.Schedule(W, ts)
+    err, scale = {}, 0.0
+    for mode in ("f32", "f16x3"):
+        W.set_math(mode)
+        worst, sq, n = 0.0, 0.0, 0
+        for i, t in enumerate(ts):
+            eps = zh.score_eps(W, s, i, dev(x)).cpu().numpy()
+            assert np.isfinite(eps).all(), (case, mode)
+            ref = O.score_model_forward(w64, x.astype(np.float64), np.float64(t) * 999.0, dtype=np.float64)
+            scale = max(scale, float(np.abs(ref).max()))
+            d = np.abs(eps.astype(np.float64) - ref)
+            worst, sq, n = max(worst, float(d.max())), sq + float((d * d).sum()), n + d.size
+        err[mode] = (worst, float(np.sqrt(sq / n)))
+    _report("f16x3_adversarial_" + case, [dict(mode=m, max_abs=e[0], rms=e[1], output_scale=scale) for m, e in err.items()])
+    assert err["f16x3"][0] <= 1.5 * err["f32"][0] + 3e-8 * max(1.0, scale), (case, err, scale)
+    assert err["f16x3"][1] <= 1.5 * err["f32"][1] + 1e-8 * max(1.0, scale), (case, err, scale)
+
+
+def test_f16x3_is_refused_for_rows_far_below_their_matrix_maximum(zh, weights0):
+    """Each matrix carries ONE power-of-two scale in the split-fp16 mode: a non-zero row whose largest weight is below 2^-8 of the
+    matrix maximum would lose bits in its small elements (low pieces fp16-denormal) - refused, like the overflow case; all-zero rows
+    (the padding of pre / post_dense, a pruned channel) are fine; the exact-fp32 mode takes everything."""
+    w = {k: v.copy() for k, v in weights0.items()}
+    w["b2_dense1.weight"][5] *= np.float32(2.0 ** -8.6)
+    W = zh.Weights(w, math="f32")
+    with pytest.raises(zh.ZedoError, match="bad argument"):
+        W.set_math("f16x3")
+    assert W.math == "f32"
+    w = {k: v.copy() for k, v in weights0.items()}
+    w["b2_dense1.weight"][5] = 0.0
+    w["post_dense.weight"][50] = 0.0
+    assert zh.Weights(w, math="f32").set_math("f16x3").math == "f16x3"
+
+
 def test_f16x3_is_refused_for_a_network_that_could_overflow_fp16(zh, weights0):
     """The split-fp16 mode stores activations as unscaled fp16 pieces (max 65504).  A network whose GroupNorm parameters
     allow activations near that range (bound: max|gamma| sqrt(31) + max|beta| along the residual path >= 32768) must be

@@ -39,6 +39,7 @@ struct zedo_weights {
     float act_bound;            // upper bound of every activation |h| the network can produce (from gamma / beta, see zedo_weights_create)
     float unscale[6];           // 2^-wshift, same order
     bool finite16;              // no NaN / inf among the six weight matrices and the GroupNorm parameters (fmax cannot see a NaN)
+    float row_ratio16;          // min over the six matrices and their non-zero rows of max|w_row| / max|w_matrix| (1 = every row as large as the largest)
 };
 
 struct zedo_schedule {
@@ -240,6 +241,19 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     auto all_finite = [&](const float *v, size_t n) {
         for (size_t q = 0; q < n; ++q) finite &= (bool)std::isfinite(v[q]);
     };
+    // The split-fp16 copy of a matrix carries ONE power-of-two scale (max |w| -> [2^13, 2^14)): a row whose largest weight is 2^-s of
+    // the matrix maximum keeps 22 - max(0, s + t - 16) significant bits in an element 2^-t below that row maximum (its low piece
+    // goes fp16-denormal).  Rows within 2^-8 of the matrix maximum (every initialisation and every GroupNorm-ed trained layer seen)
+    // keep fp32-level accuracy; zedo_weights_set_math refuses the mode below that (ZEDO_F16X3_MIN_ROW_RATIO).
+    float row_ratio = 1.0f;
+    auto row_ratio_of = [&](const float *wm, size_t rows, size_t cols, float mat_max) {
+        if (!(mat_max > 0.f)) return;
+        for (size_t r = 0; r < rows; ++r) {
+            float rm = 0.f;
+            for (size_t c = 0; c < cols; ++c) rm = std::fmax(rm, std::fabs(wm[r * cols + c]));
+            if (rm > 0.f) row_ratio = std::fmin(row_ratio, rm / mat_max);       // all-zero rows carry no information to lose
+        }
+    };
     auto gn_bound_of = [&](const float *g, const float *be, size_t n) {
         float gm = 0.f, bm = 0.f;
         for (size_t q = 0; q < n; ++q) { gm = std::fmax(gm, std::fabs(g[q])); bm = std::fmax(bm, std::fabs(be[q])); }
@@ -254,6 +268,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     for (size_t n = 0; n < H; ++n) memcpy(&img[o_Wpre + n * XLD], w_pre + n * J3, sizeof(float) * J3);
     for (size_t q = 0; q < H * J3; ++q) wmax_hid_tmp[4] = std::fmax(wmax_hid_tmp[4], std::fabs(w_pre[q]));
     all_finite(w_pre, H * J3);
+    row_ratio_of(w_pre, H, J3, wmax_hid_tmp[4]);
     memcpy(&img[o_gamma], g_pre, sizeof(float) * H);
     memcpy(&img[o_beta], be_pre, sizeof(float) * H);
     memcpy(&img[o_Ws], w_s, sizeof(float) * E * E);
@@ -268,6 +283,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
         for (size_t q = 0; q < H * H; ++q) wm = std::fmax(wm, std::fabs(w[q]));
         all_finite(w, H * H);
         wmax_hid_tmp[l - 1] = wm;
+        row_ratio_of(w, H, H, wm);
         memcpy(&img[o_Wt + (size_t)l * H * E], wt, sizeof(float) * H * E);
         memcpy(&img[o_gamma + (size_t)l * H], g, sizeof(float) * H);
         memcpy(&img[o_beta + (size_t)l * H], be, sizeof(float) * H);
@@ -279,6 +295,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     memcpy(&img[o_Wpost], w_post, sizeof(float) * J3 * H);
     for (size_t q = 0; q < (size_t)J3 * H; ++q) wmax_hid_tmp[5] = std::fmax(wmax_hid_tmp[5], std::fabs(w_post[q]));
     all_finite(w_post, (size_t)J3 * H);
+    row_ratio_of(w_post, J3, H, wmax_hid_tmp[5]);
     memcpy(&img[o_bpost], b_post, sizeof(float) * J3);
 
     zedo_weights *w = new (std::nothrow) zedo_weights();
@@ -289,6 +306,7 @@ extern "C" int zedo_weights_create(const float *h_params, size_t n_floats, int n
     for (int l = 0; l < 6; ++l) { w->wmax_hid[l] = wmax_hid_tmp[l]; w->unscale[l] = 1.0f; }
     w->act_bound = std::fmax(std::fmax(gn_bound[1], gn_bound[3]), gn_bound[0] + gn_bound[2] + gn_bound[4]);
     w->finite16 = finite;
+    w->row_ratio16 = row_ratio;
     hipError_t e = hipMalloc(&w->d_all, off * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&w->d_scratch, sizeof(float) * ((size_t)2 * ROW_PAD * EMB + ROW_PAD));
     if (e != hipSuccess) { (void)hipFree(w->d_all); delete w; return (int)e; }
@@ -328,6 +346,8 @@ extern "C" int zedo_weights_set_math(zedo_weights_t *w, int mode, void *stream) 
         // activations are stored as UNSCALED fp16 pieces: refuse the mode for a network whose GroupNorm parameters allow an
         // activation near the fp16 range (65504) instead of overflowing silently (trained checkpoints: O(10))
         if (!(w->act_bound < 32768.0f)) return ZEDO_E_BADARG;
+        // one scale per matrix: rows far below the matrix maximum would lose bits (see zedo_weights_create)
+        if (!(w->row_ratio16 >= 1.0f / 256.0f)) return ZEDO_E_BADARG;
         const size_t per = (size_t)HID * HID * 2;                                 // uint16 per hidden layer
         HIPCHK(hipMalloc(&w->d_W16, sizeof(uint16_t) * (4 * per + (size_t)HID * XLD * 2 + (size_t)XLD * HID * 2)));
         hipError_t e = hipSuccess;
