@@ -166,7 +166,7 @@ def roofline_f16x3(h2, rows_launch):
     dma_bytes = sum((r / bm) * (1024 / bn) * (bm + bn) * 64 * 64 for bm, bn, r in split)
     shape = " + ".join(f"{bm}x{bn} tiles on {r} rows" for bm, bn, r in split)
     t = h2["avg_ms"] * 1e-3
-    return dict(bound="mfma", kernel=f"zedo::layer16_pair_kernel / layer16_small_kernel ({shape}; split-fp16 operands, 3 x v_mfma_f32_32x32x16_f16 per 16-k block)",
+    return dict(bound="mfma", kernel=f"zedo::layer16_pair_kernel / layer16_small_kernel ({shape}; split-fp16 operands as k-block-major planes, 3 x v_mfma_f32_32x32x16_f16 per 16-k block)",
                 achieved=round(issued / t / 1e12, 1), peak=2500.0, unit="TFLOP/s", frac=round(issued / t / 1e12 / 2500.0, 4),
                 traffic=f16x3_traffic(rows_launch), fp32_equivalent_tflops=round(2.0 * rows_launch * 1024 * 1024 / t / 1e12, 1),
                 avg_launch_ms=round(h2["avg_ms"], 4), sampled_launches=h2["samples"], launches=h2["launches"],
@@ -176,9 +176,11 @@ def roofline_f16x3(h2, rows_launch):
                 lds_dma_sustained_tb_per_s=(round(16.0 * 256 * ghz * 1e9 / 1e12, 2) if ghz else None),
                 vmem_model_ms=round(((rows_launch / 32) * 32 * 64 * 3 * 32 + dma_bytes / 1024 * 65 + rows_launch * 4096 / 1024 * 187)
                                     / 1024 / (ghz * 1e9) * 1e3, 4) if ghz else None,
-                note="power management holds the shader clock near 1.8 GHz under the dense fp16 MFMA stream; on this pipe a SIMD's "
-                     "vector-memory instructions serialise with its MFMAs (65 cycles per 1 KB LDS-DMA, 187 per 1 KB store, "
-                     "profiles/coissue_f16_r03.txt): vmem_model_ms = (MFMA + LDS-DMA + store cycles) / 1024 SIMDs at the kernel's clock")
+                note="power management holds the shader clock at 1.5-1.85 GHz under the dense fp16 MFMA stream (lower the busier the pipe). "
+                     "vmem_model_ms = (MFMA + LDS-DMA + store issue cycles) / 1024 SIMDs at the kernel's clock: round 3's additive model, kept "
+                     "for continuity - round 5 showed that an LDS-DMA stalls only the wave that issues it (profiles/vmem_issue_r05.txt); what "
+                     "the layer sits on is the MFMA floor at that clock (165-198 us), the DMA stream of the 128 x 256 tiles (91 us alone with "
+                     "k-block-major planes, 154 us before) and the epilogue, which overlap only partly (profiles/f16x3_designs_r05.txt)")
 
 
 def f16x3_traffic(rows_launch):
