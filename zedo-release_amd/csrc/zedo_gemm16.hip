@@ -232,6 +232,23 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
         const size_t rgrp = (size_t)a.ldo * 64;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
+            constexpr int ITEMS = (SR * CG + NT - 1) / NT;         // (row, 16-channel group) items per thread
+            static_assert((SR * CG) % NT == 0, "write-out shape");
+            // residual (EPI_GN_SILU_RES): ALL of this thread's loads of the phase, issued BEFORE the phase's GroupNorm / SiLU arithmetic
+            // (round 5: they used to follow it, one exposed memory round trip per phase - the residual layers were 40 us per launch
+            // slower than the plain ones); they are consumed after the stage barrier.  `res` may alias `out`: the rows of phase j are
+            // not written before phase j's own stores, which follow these loads in program order.
+            f16x8 rres[EPI == EPI_GN_SILU_RES ? ITEMS : 1][4];
+            if constexpr (EPI == EPI_GN_SILU_RES) {
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+                    const int qi = it * NT + tid, sr = qi / CG, cg = qi % CG;
+                    const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
+                    const size_t off = (size_t)grow * 64 + (size_t)cg * rgrp;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rres[it][q] = *reinterpret_cast<const f16x8 *>(rbase + off + 16 * q);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 float o[16];
@@ -255,22 +272,6 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
                 }
             }
             __syncthreads();
-            constexpr int ITEMS = (SR * CG + NT - 1) / NT;         // (row, 16-channel group) items per thread
-            static_assert((SR * CG) % NT == 0, "write-out shape");
-            // residual (EPI_GN_SILU_RES): ALL of this thread's loads first - the accumulators are dead by now, the registers are
-            // there - so that one memory round trip is exposed per phase, not one per item (`res` may alias `out`: the compiler
-            // must not, and does not, move a later item's load above an earlier item's store by itself)
-            f16x8 rres[EPI == EPI_GN_SILU_RES ? ITEMS : 1][4];
-            if constexpr (EPI == EPI_GN_SILU_RES) {
-#pragma unroll
-                for (int it = 0; it < ITEMS; ++it) {
-                    const int qi = it * NT + tid, sr = qi / CG, cg = qi % CG;
-                    const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
-                    const size_t off = (size_t)grow * 64 + (size_t)cg * rgrp;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) rres[it][q] = *reinterpret_cast<const f16x8 *>(rbase + off + 16 * q);
-                }
-            }
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 const int qi = it * NT + tid, sr = qi / CG, cg = qi % CG;
