@@ -11,6 +11,13 @@
 
 using namespace zedo;
 
+// the split-K reduce of post_dense lives in zedo_geom.hip; this harness never reaches it (LayerArgs::scratch stays null)
+namespace zedo {
+hipError_t launch_post_reduce(float *, const float *, const float *, float, float, int, float *, const float *, float *, int, int, int, int, long long, hipStream_t) {
+    return hipErrorNotSupported;
+}
+}
+
 __global__ __launch_bounds__(256) void mfma_peak_kernel(float *out, int iters, long long *clk) {
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;

@@ -764,7 +764,7 @@ hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStr
 
 #ifdef ZEDO_UBENCH
 // ---- variant table for tools/ubench/ubench_gemm.hip ----
-constexpr int UBENCH_NVAR = 51;
+constexpr int UBENCH_NVAR = 57;
 static const char *variant_name(int v) {
     switch (v) {
         case 0: return "product launch_layer (128x128 BK16 x3/CU + 32x128 remainder, one launch)";
@@ -818,6 +818,12 @@ static const char *variant_name(int v) {
         case 48: return "32x128 4 waves ring 2 SCHED 3 (3 WG/CU)";
         case 49: return "128x128 4 waves SCHED 3 lb(256,2)";
         case 50: return "64x128 4 waves (2x2: 32x64 per wave) ring 2 SCHED 3";
+        case 51: return "= 30 (product big tile, plain) with K summed as 4 quarter chains (KQ 4)";
+        case 52: return "128x128 8 waves (2x4) BK16 SCHED 1, 6 waves/SIMD, GN_SILU_RES (product big tile, residual)";
+        case 53: return "= 52 with K summed as 4 quarter chains (KQ 4)";
+        case 54: return "64x64 4 waves ring 4 SCHED 1 (product tile up to 1 024 rows) with KQ 4";
+        case 55: return "= 51 (KQ 4) at 2 workgroups per CU (no spills)";
+        case 56: return "= 53 (KQ 4, residual) at 4 waves/SIMD (no spills)";
     }
     return "?";
 }
@@ -874,6 +880,12 @@ static hipError_t launch_variant(const LayerArgs &a, int v, hipStream_t st) {
         case 48: return launch_cfg<32, 128, 1, 4, EPI_GN_SILU, 2, 0, 32, 3>(a, st);
         case 49: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 3, 2>(a, st);
         case 50: return launch_cfg<64, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 3>(a, st);
+        case 51: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 16, 1, 3, 0, 4>(a, st);
+        case 52: return launch_cfg<128, 128, 2, 4, EPI_GN_SILU_RES, 2, 0, 16, 1, 6>(a, st);
+        case 53: return launch_cfg<128, 128, 2, 4, EPI_GN_SILU_RES, 2, 0, 16, 1, 6, 0, 4>(a, st);
+        case 54: return launch_cfg<64, 64, 2, 2, EPI_GN_SILU, 4, 0, 32, 1, 1, 0, 4>(a, st);
+        case 55: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 16, 1, 2, 0, 4>(a, st);
+        case 56: return launch_cfg<128, 128, 2, 4, EPI_GN_SILU_RES, 2, 0, 16, 1, 4, 0, 4>(a, st);
     }
     return hipErrorInvalidValue;
 }
