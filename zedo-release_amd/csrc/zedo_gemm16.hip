@@ -292,13 +292,34 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
 #pragma unroll
                     for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(obase + off + 16 * q) = v[q];
                 } else {
+                    // the item's 64 bytes of planes {h 0-7, h 8-15, l 0-7, l 8-15} go back into its own four stage slots ...
                     f16x8 h0, l0, h1, l1;
                     split_f16x8(v[0], v[1], h0, l0);
                     split_f16x8(v[2], v[3], h1, l1);
-                    *reinterpret_cast<f16x8 *>(obase + off) = h0;
-                    *reinterpret_cast<f16x8 *>(obase + off + 16) = h1;
-                    *reinterpret_cast<f16x8 *>(obase + off + 32) = l0;
-                    *reinterpret_cast<f16x8 *>(obase + off + 48) = l1;
+                    float *sp = S + sr * BN;
+                    *reinterpret_cast<f16x8 *>(sp + (((cg * 4 + 0) ^ (sr & 7)) << 2)) = h0;
+                    *reinterpret_cast<f16x8 *>(sp + (((cg * 4 + 1) ^ (sr & 7)) << 2)) = h1;
+                    *reinterpret_cast<f16x8 *>(sp + (((cg * 4 + 2) ^ (sr & 7)) << 2)) = l0;
+                    *reinterpret_cast<f16x8 *>(sp + (((cg * 4 + 3) ^ (sr & 7)) << 2)) = l1;
+                }
+            }
+            if (!a.out_f32) {
+                // ... and leave with FOUR LANES PER 64-BYTE ROW PIECE: instruction n of a wave writes 4 rows x 4 channel groups, each group's
+                // rows 256 contiguous bytes.  (Round 5, tools/ubench/ubench_epi_pattern.hip: with the planes k-block-major the old map -
+                // one lane = one row piece, instruction q = its bytes 16 q .. 16 q + 15 - wrote 64 separate 16-byte pieces per instruction
+                // and the stores of one layer alone took 66 us; this map 31 us.)  Wave-local: item (it, lane) of the loop above covers
+                // rows it * NT / CG + wid * 64 / CG .. and all CG groups, the same rows this wave moves out here; LDS operations of one
+                // wave execute in order, so no barrier separates the write-back from these reads.
+                static_assert(CG == 4 || CG == 8 || CG == 16, "quad-dense write-out: 4 rows x 4 groups per instruction");
+                constexpr int RPW = 64 / CG;                   // rows per wave per item round
+                const int q = lane & 3, c4 = (lane >> 2) & 3, r4 = lane >> 4;
+#pragma unroll
+                for (int n = 0; n < ITEMS * 4; ++n) {
+                    const int it = n >> 2, blk = n & 3;
+                    const int cg = c4 + 4 * (blk % (CG / 4)), sr = it * (NT / CG) + wid * RPW + r4 + 4 * (blk / (CG / 4));
+                    const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
+                    const f16x8 piece = *reinterpret_cast<const f16x8 *>(S + sr * BN + (((cg * 4 + q) ^ (sr & 7)) << 2));
+                    *reinterpret_cast<f16x8 *>(obase + (size_t)cg * ogrp + (size_t)grow * 64 + 16 * q) = piece;
                 }
             }
             if (j + 1 < TJ) __syncthreads();
