@@ -230,10 +230,18 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
         char *obase = reinterpret_cast<char *>(a.out) + (pl_out ? ((size_t)(n0 >> 4) * a.ldo + m0) * 64 : (size_t)m0 * a.N * 4 + (size_t)n0 * 4);
         const char *rbase = reinterpret_cast<const char *>(a.res) + ((size_t)(n0 >> 4) * a.ldo + m0) * 64;
         const size_t rgrp = (size_t)a.ldo * 64;
+        // (row, 16-channel group) items: in round `it` wave `wid` owns stage rows it * NT / CG + wid * 64 / CG .. + 64 / CG - 1 and all CG
+        // groups; within the wave lane = (row & 3) | (group & 3) << 2 | the rest: the 16 lanes of one LDS pass then hit 16 different
+        // 16-byte slots of the swizzled stage rows (slot = (4 group + q) ^ (row & 7); with lane = group | row << 4, the map until
+        // round 5, they hit four - SQ_LDS_BANK_CONFLICT 5.6 M cycles per launch once the write-back below doubled those accesses)
+        constexpr int ITEMS = (SR * CG + NT - 1) / NT;             // items per thread
+        static_assert((SR * CG) % NT == 0 && (CG == 4 || CG == 8 || CG == 16), "write-out shape");
+        constexpr int RPW = 64 / CG;                               // rows per wave per round
+        const int item_cg = ((lane >> 2) & 3) + 4 * ((lane >> 4) % (CG / 4));
+        const int item_r = wid * RPW + (lane & 3) + 4 * ((lane >> 4) / (CG / 4));
+        auto item_row = [&](int it) { return it * (NT / CG) + item_r; };
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-            constexpr int ITEMS = (SR * CG + NT - 1) / NT;         // (row, 16-channel group) items per thread
-            static_assert((SR * CG) % NT == 0, "write-out shape");
             // residual (EPI_GN_SILU_RES): ALL of this thread's loads of the phase, issued BEFORE the phase's GroupNorm / SiLU arithmetic
             // (round 5: they used to follow it, one exposed memory round trip per phase - the residual layers were 40 us per launch
             // slower than the plain ones); they are consumed after the stage barrier.  `res` may alias `out`: the rows of phase j are
@@ -242,7 +250,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
             if constexpr (EPI == EPI_GN_SILU_RES) {
 #pragma unroll
                 for (int it = 0; it < ITEMS; ++it) {
-                    const int qi = it * NT + tid, sr = qi / CG, cg = qi % CG;
+                    const int sr = item_row(it), cg = item_cg;
                     const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
                     const size_t off = (size_t)grow * 64 + (size_t)cg * rgrp;
 #pragma unroll
@@ -274,7 +282,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
-                const int qi = it * NT + tid, sr = qi / CG, cg = qi % CG;
+                const int sr = item_row(it), cg = item_cg;
                 const int grow = (sr >> 5) * TM + j * 32 + (sr & 31);
                 const size_t off = (size_t)grow * orow + (size_t)cg * ogrp;
                 f32x4 v[4];
@@ -310,8 +318,6 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
                 // and the stores of one layer alone took 66 us; this map 31 us.)  Wave-local: item (it, lane) of the loop above covers
                 // rows it * NT / CG + wid * 64 / CG .. and all CG groups, the same rows this wave moves out here; LDS operations of one
                 // wave execute in order, so no barrier separates the write-back from these reads.
-                static_assert(CG == 4 || CG == 8 || CG == 16, "quad-dense write-out: 4 rows x 4 groups per instruction");
-                constexpr int RPW = 64 / CG;                   // rows per wave per item round
                 const int q = lane & 3, c4 = (lane >> 2) & 3, r4 = lane >> 4;
 #pragma unroll
                 for (int n = 0; n < ITEMS * 4; ++n) {
