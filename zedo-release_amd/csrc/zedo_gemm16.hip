@@ -14,14 +14,17 @@
 // 2^14)) undone exactly in the epilogue's first fma; activations are O(1..10) and unscaled; the matrix pipe honours fp16
 // denormals (probed), so tiny pieces cost an absolute 3e-8, not a flush.
 //
-// What bounds it (MI355X; tools/ubench/ubench_f16x3.hip, ubench_coissue.hip -DMFMA_F16=1; profiles/ubench_f16x3*_r03.txt,
-// coissue_f16_r03.txt): three fp16 MFMAs are 96 matrix-pipe cycles against 512 for the eight exact-fp32 MFMAs of the same
-// block, but (i) under a dense fp16 MFMA stream power management holds the shader clock at 1.7-1.85 GHz (2.36 for the fp32
-// kernel): the MFMA floor of a 50k-row layer is ~165 us, not 127; (ii) beside an fp16 MFMA a SIMD issues plain VALU for free,
-// but every vector-memory instruction at its full stand-alone price - 65 cycles per 1 KB LDS-DMA or load, 187 per 1 KB
-// store - wherever it is placed: a layer costs MFMA cycles + VMEM cycles, and the operands still cross L2 -> LDS at 4 bytes
-// per element.  The tile shape sets that share (see layer16_pair_kernel); the epilogue is scalar fp32 (no v_pk_*: those
-// cost ~9 cycles each here, the file is built with -fno-slp-vectorize).
+// What bounds it (MI355X; tools/ubench/ubench_f16x3.hip, ubench_vmem_issue.hip, ubench_dma_layout.hip, ubench_epi_pattern.hip;
+// profiles/f16x3_designs_r05.txt): three fp16 MFMAs are 96 matrix-pipe cycles against 512 for the eight exact-fp32 MFMAs of the same
+// block, but (i) under a dense fp16 MFMA stream power management holds the shader clock at 1.5-1.85 GHz (2.36 for the fp32 kernel;
+// the busier the pipe the lower): the MFMA floor of a 50k-row layer is 165-198 us, not 127; (ii) the operands still cross L2 -> LDS
+// at 4 bytes per element: the DMA stream of the 128 x 256 tiles alone takes 91 us, the stores alone 31 us, the epilogue's VALU
+// ~50 us per SIMD, and they overlap only partly.  A vector-memory instruction stalls the wave that issues it (an LDS-DMA ~70
+// cycles, 100-130 of MFMA issue when the issuer is the MFMA wave itself), not the other waves of its SIMD (round 5; round 3 had
+// read its co-issue table as "VMEM serialises with MFMA").  Plain VALU beside an fp16 MFMA is free; the epilogue is scalar fp32
+// (no v_pk_*: those cost ~9 cycles each here, the file is built with -fno-slp-vectorize).  Address patterns matter as much as
+// counts: planes are k-block-major so that every DMA instruction reads 1 KB of contiguous memory, and the epilogue writes every
+// 64-byte row piece with four adjacent lanes (see the write-out below).
 //
 // Mapping, LDS layout and loop are the exact-fp32 kernel's (zedo_gemm.hip) with 64-byte LDS rows:
 //   i = output CHANNEL (rows of W, MFMA A operand), j = BATCH ROW (rows of X, B operand); lane (li, kh) holds k = 8 kh .. 8 kh + 7
@@ -437,13 +440,13 @@ __device__ __forceinline__ void layer16_body(const Layer16Args &a, const int bid
 // One launch, two tile shapes (as layer_pair_kernel of zedo_gemm.hip): workgroups [0, nbig) run BIG_M x BIG_N tiles on the rows
 // that fill whole rounds of the chip, the rest 64x64 tiles on the remainder rows, which back-fill CUs as the big tiles
 // drain (64x64: the tail of the launch is one small tile's latency, and a 64x64 tile's is the shortest).  Either count may be zero.
-// The big tile is 128 rows x 256 channels (four waves of 64 x 128, 230 registers, two workgroups per CU, 67 KB of LDS): on this
-// pipe every vector-memory instruction of a SIMD - LDS-DMA, load, store - serialises with its MFMAs at full price (65 cycles
-// per 1 KB LDS-DMA, 187 per 1 KB store; plain VALU is free; profiles/coissue_f16_r03.txt), so the layer's time is MFMA cycles +
-// VMEM cycles, and the tile shape sets the VMEM share: LDS-DMA cycles / MFMA cycles = 43 (BM + BN) / (BM BN) = 0.68 for
-// 128x128, 0.51 for 128x256 (measured 341 -> 313 us per layer, profiles/ubench_f16x3_tiles_r03.txt), 0.34 for 256x256
-// (291 us in the microbenchmark; eight waves, one workgroup per CU - tried in the product with the remainder as a launch of
-// its own: 0.354 ms per layer against 0.335, the epilogue of the only resident workgroup is fully exposed: not adopted).
+// The big tile is 128 rows x 256 channels (four waves of 64 x 128, 230 registers, two workgroups per CU, 67 KB of LDS): every wave
+// issues its own LDS-DMA (6 per k block) between its MFMAs, which costs it 100-130 cycles of MFMA issue each while the
+// co-resident workgroup's wave on the same SIMD keeps the pipe busy; the tile shape sets how many there are per MFMA:
+// LDS-DMA / MFMA instructions = 43 (BM + BN) / (BM BN) x ... = 0.68 for 128x128, 0.51 for 128x256 (measured 341 -> 313 us per
+// layer, profiles/ubench_f16x3_tiles_r03.txt), 0.34 for 256x256 (291 us in the microbenchmark; eight waves, one workgroup per
+// CU - tried in the product with the remainder as a launch of its own: 0.354 ms per layer against 0.335, the epilogue of the
+// only resident workgroup is fully exposed: not adopted; so were round 5's loader-wave and tile ping-pong designs).
 // BIG_N = 128: batches between 2 048 and 8 192 rows take 128x128 tiles (three workgroups per CU) - see launch_layer16.
 constexpr int BIG_M = 128;
 template <int EPI, int BIG_N>
