@@ -88,7 +88,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     static_assert(TM % 32 == 0 && TN % 32 == 0 && IA >= 1 && IB >= 1 && (BN * CPR) % (64 * NW) == 0 && (BM * CPR) % (64 * NW) == 0, "tile");
     constexpr int SLOT = (BN + BM) * RB;                              // one ring slot: [BN rows of W][BM rows of X]
     constexpr int SR = WM * 32;                                       // epilogue stage rows per phase
-    static_assert(NBUF >= 2 && NBUF % 2 == 0 && (NBUF - 1) * IPW <= 63, "ring depth (fragment set = slot & 1; 6-bit vmcnt)");
+    static_assert(NBUF >= 2 && (NBUF - 1) * IPW <= 63, "ring depth (6-bit vmcnt)");
     constexpr int RING_B = NBUF * SLOT, STAGE_B = SR * BN * 4, BODY_B = RING_B > STAGE_B ? RING_B : STAGE_B;
 
     extern __shared__ __attribute__((aligned(16))) char smem16[];
@@ -102,24 +102,34 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     // instruction reads 1 KB of memory (16 rows x 64 bytes; round 5 - with [row][k/16] rows 4 KB apart the same stream ran at 0.6x)
     const size_t wkb = (size_t)a.N * RB, xkb = (size_t)a.ldx * RB;   // bytes between k blocks of W / X
     const char *Wbase = reinterpret_cast<const char *>(a.W) + (size_t)n0 * RB;
+#ifdef ZEDO_EXP_XREUSE     // timing experiment of the harness only (wrong values): every row tile reads the first 256 rows - X always hits the L2
+    const char *Xbase = reinterpret_cast<const char *>(a.X) + (size_t)(m0 & 255) * RB;
+#else
     const char *Xbase = reinterpret_cast<const char *>(a.X) + (size_t)m0 * RB;
+#endif
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem16;
 
     // DMA instruction p of this wave moves the 16-byte chunks g = (wid * I + p) * 64 + lane of the tile's block: LDS row
     // g / 4, position g % 4, which holds source chunk (g % 4) ^ swz(row)
-    unsigned woff[IA], xoff[IB];
-#pragma unroll
-    for (int p = 0; p < IA; ++p) { const int g = (wid * IA + p) * 64 + lane, r = g / CPR; woff[p] = (unsigned)(r * RB + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
-#pragma unroll
-    for (int p = 0; p < IB; ++p) { const int g = (wid * IB + p) * 64 + lane, r = g / CPR; xoff[p] = (unsigned)(r * RB + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
+    // A wave's pieces of one operand are consecutive: piece p is rows (wid * I + p) * 16 .. + 15, i.e. source offset AND LDS offset of
+    // piece 0 + 1024 p (the swizzle term (r >> 2) & 3 = (lane / 16) & 3 does not depend on p): they go out behind one M0 write (dma16n).
+    static_assert((IA == 1 || IA == 2 || IA == 4) && (IB == 1 || IB == 2 || IB == 4), "pieces per wave per operand");
+    unsigned woff0, xoff0;
+    { const int g = wid * IA * 64 + lane, r = g / CPR; woff0 = (unsigned)(r * RB + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
+    { const int g = wid * IB * 64 + lane, r = g / CPR; xoff0 = (unsigned)(r * RB + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
     auto dma = [&](int kb, int slot) {
         const char *wk = Wbase + (size_t)kb * wkb, *xk = Xbase + (size_t)kb * xkb;
+#ifdef ZEDO_NO_DMA_GROUP   // A/B knob of the harness: one M0 write per piece, as until round 5
 #pragma unroll
-        for (int p = 0; p < IA; ++p) dma16(wk, woff[p], lds0 + slot * SLOT + (wid * IA + p) * 1024);
+        for (int p = 0; p < IA; ++p) dma16(wk, woff0 + p * 1024, lds0 + slot * SLOT + (wid * IA + p) * 1024);
         if constexpr (!XF32) {
 #pragma unroll
-            for (int p = 0; p < IB; ++p) dma16(xk, xoff[p], lds0 + slot * SLOT + BN * RB + (wid * IB + p) * 1024);
+            for (int p = 0; p < IB; ++p) dma16(xk, xoff0 + p * 1024, lds0 + slot * SLOT + BN * RB + (wid * IB + p) * 1024);
         }
+#else
+        dma16n<IA>(wk, woff0, lds0 + slot * SLOT + wid * IA * 1024);
+        if constexpr (!XF32) dma16n<IB>(xk, xoff0, lds0 + slot * SLOT + BN * RB + wid * IB * 1024);
+#endif
     };
 
     f32x16 acc[TI][TJ];
@@ -202,19 +212,27 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     //   block kb in slot kb % NBUF, its fragments in set kb & 1:
     //       vmcnt((NBUF-2) blocks); barrier   <- every wave has read block kb (its fragments are in registers), block kb+1 has landed
     //       DMA(block kb+NBUF -> slot of kb);  read(block kb+1) -> the other set;  MFMA(block kb)
-    for (int kb0 = 0; kb0 < KB; kb0 += NBUF) {
+    // slots and fragment sets are both back at 0 after U blocks: unrolled by U every LDS offset is an instruction immediate
+    constexpr int U = NBUF % 2 == 0 ? NBUF : 2 * NBUF;
+    auto step = [&](int kb, int slot, int set) __attribute__((always_inline)) {
+        // hipcc does not count the LDS-DMA in its vmcnt bookkeeping: wait explicitly
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
+        __syncthreads();
+        if constexpr (!XF32) dma(min(kb + NBUF, KB - 1), slot);     // branch-free: past the end it refills a slot nobody reads again
+        fread(set ^ 1, (slot + 1) % NBUF);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(set);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int kb0 = 0;
+    for (; kb0 + U <= KB; kb0 += U) {
 #pragma unroll
-        for (int slot = 0; slot < NBUF; ++slot) {
-            const int kb = kb0 + slot;
-            // hipcc does not count the LDS-DMA in its vmcnt bookkeeping: wait explicitly
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
-            __syncthreads();
-            if constexpr (!XF32) dma(min(kb + NBUF, KB - 1), slot);     // branch-free: past the end it refills a slot nobody reads again
-            fread((slot & 1) ^ 1, (slot + 1) % NBUF);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(slot & 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int u = 0; u < U; ++u) step(kb0 + u, u % NBUF, u & 1);
+    }
+    if constexpr (NBUF % 2 != 0) {      // odd ring (3): K / 16 is a multiple of 4, not of 6 - the last 2 or 4 blocks (uniform branches)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (kb0 + u < KB) step(kb0 + u, u % NBUF, u & 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();           // drain the trailing DMA before the ring becomes the epilogue stage
@@ -449,12 +467,15 @@ __device__ __forceinline__ void layer16_body(const Layer16Args &a, const int bid
 // only resident workgroup is fully exposed: not adopted; so were round 5's loader-wave and tile ping-pong designs).
 // BIG_N = 128: batches between 2 048 and 8 192 rows take 128x128 tiles (three workgroups per CU) - see launch_layer16.
 constexpr int BIG_M = 128;
+#ifndef ZEDO_BIG_NBUF16
+#define ZEDO_BIG_NBUF16 3      // ring depth of the 128 x 256 tile: 3 x 24 KB = 72 KB (the 64 KB epilogue stage fits inside), 2 workgroups per CU = 150 KB
+#endif
 template <int EPI, int BIG_N>
 __global__ __launch_bounds__(256, BIG_N == 256 ? 2 : 3) void layer16_pair_kernel(Layer16Args big, Layer16Args small, int nbig) {
     long long c0 = 0, w0 = 0;
     const bool probe = big.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     if (probe) { c0 = clock64(); w0 = wall_clock64(); }
-    if ((int)blockIdx.x < nbig) layer16_body<BIG_M, BIG_N, 2, 2, EPI, 2>(big, blockIdx.x, nbig);
+    if ((int)blockIdx.x < nbig) layer16_body<BIG_M, BIG_N, 2, 2, EPI, BIG_N == 256 ? ZEDO_BIG_NBUF16 : 2>(big, blockIdx.x, nbig);
     else layer16_body<64, 64, 2, 2, EPI, 4>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     if (probe) { big.clk[0] = clock64() - c0; big.clk[1] = wall_clock64() - w0; }
 }
@@ -494,7 +515,7 @@ static hipError_t launch_thin16(K kern, std::atomic<bool> *attr_done, size_t lds
 
 template <int EPI, int BIG_N>
 static hipError_t launch_pair16(const Layer16Args &big, const Layer16Args &small, hipStream_t st) {
-    constexpr size_t ring_big = 2 * (BIG_M + BIG_N) * 64, stage_big = (size_t)64 * BIG_N * 4, par_big = 3 * BIG_N * sizeof(float);
+    constexpr size_t ring_big = (BIG_N == 256 ? ZEDO_BIG_NBUF16 : 2) * (BIG_M + BIG_N) * 64, stage_big = (size_t)64 * BIG_N * 4, par_big = 3 * BIG_N * sizeof(float);
     constexpr size_t ring_small = 4 * (64 + 64) * 64, stage_small = (size_t)64 * 64 * 4, par_small = 3 * 64 * sizeof(float);
     constexpr size_t lds_big = (ring_big > stage_big ? ring_big : stage_big) + par_big;
     constexpr size_t lds_small = (ring_small > stage_small ? ring_small : stage_small) + par_small;

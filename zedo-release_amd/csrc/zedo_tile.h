@@ -61,6 +61,24 @@ __device__ __forceinline__ void dma16(const char *sbase, unsigned voff, unsigned
                  : "memory");
 }
 
+// N (1, 2 or 4) such DMAs of CONSECUTIVE 1-KB pieces - source and LDS destination both advance by 1 KB per piece - behind ONE M0
+// write: the instruction's 13-bit immediate offset is added to the global AND the LDS address (checked on the device by
+// tools/ubench/ubench_dma_group.hip, which also measured the burst of a 24-MFMA block: six separate dma16 cost the issuing wave
+// 39 / 31 cycles each at 1 / 2 waves per SIMD, 4 + 2 behind two M0 writes 20 / 18).
+template <int N>
+__device__ __forceinline__ void dma16n(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
+    static_assert(N == 1 || N == 2 || N == 4, "pieces per M0 write (offsets up to 3072 fit the 13-bit signed field)");
+    unsigned keep;
+    if constexpr (N == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\tglobal_load_lds_dwordx4 %2, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %2, %1 offset:2048\n\tglobal_load_lds_dwordx4 %2, %1 offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(sbase), "v"(voff), "s"(lds_byte_addr) : "memory");
+    else if constexpr (N == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\tglobal_load_lds_dwordx4 %2, %1 offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(sbase), "v"(voff), "s"(lds_byte_addr) : "memory");
+    else dma16(sbase, voff, lds_byte_addr);
+}
+
 __device__ __forceinline__ float silu_fast(float y) {
     // y * sigmoid(y) with hardware exp2 / rcp (each <= 1 ulp): |rel err| <= ~3e-7
     return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.44269504088896340736f));
