@@ -470,12 +470,15 @@ constexpr int BIG_M = 128;
 #ifndef ZEDO_BIG_NBUF16
 #define ZEDO_BIG_NBUF16 3      // ring depth of the 128 x 256 tile: 3 x 24 KB = 72 KB (the 64 KB epilogue stage fits inside), 2 workgroups per CU = 150 KB
 #endif
+#ifndef ZEDO_MID_NBUF16
+#define ZEDO_MID_NBUF16 2      // ring depth of the 128 x 128 tile (batches of 2 048 - 8 192 rows, three workgroups per CU)
+#endif
 template <int EPI, int BIG_N>
 __global__ __launch_bounds__(256, BIG_N == 256 ? 2 : 3) void layer16_pair_kernel(Layer16Args big, Layer16Args small, int nbig) {
     long long c0 = 0, w0 = 0;
     const bool probe = big.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     if (probe) { c0 = clock64(); w0 = wall_clock64(); }
-    if ((int)blockIdx.x < nbig) layer16_body<BIG_M, BIG_N, 2, 2, EPI, BIG_N == 256 ? ZEDO_BIG_NBUF16 : 2>(big, blockIdx.x, nbig);
+    if ((int)blockIdx.x < nbig) layer16_body<BIG_M, BIG_N, 2, 2, EPI, BIG_N == 256 ? ZEDO_BIG_NBUF16 : ZEDO_MID_NBUF16>(big, blockIdx.x, nbig);
     else layer16_body<64, 64, 2, 2, EPI, 4>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     if (probe) { big.clk[0] = clock64() - c0; big.clk[1] = wall_clock64() - w0; }
 }
@@ -515,7 +518,7 @@ static hipError_t launch_thin16(K kern, std::atomic<bool> *attr_done, size_t lds
 
 template <int EPI, int BIG_N>
 static hipError_t launch_pair16(const Layer16Args &big, const Layer16Args &small, hipStream_t st) {
-    constexpr size_t ring_big = (BIG_N == 256 ? ZEDO_BIG_NBUF16 : 2) * (BIG_M + BIG_N) * 64, stage_big = (size_t)64 * BIG_N * 4, par_big = 3 * BIG_N * sizeof(float);
+    constexpr size_t ring_big = (BIG_N == 256 ? ZEDO_BIG_NBUF16 : ZEDO_MID_NBUF16) * (BIG_M + BIG_N) * 64, stage_big = (size_t)64 * BIG_N * 4, par_big = 3 * BIG_N * sizeof(float);
     constexpr size_t ring_small = 4 * (64 + 64) * 64, stage_small = (size_t)64 * 64 * 4, par_small = 3 * 64 * sizeof(float);
     constexpr size_t lds_big = (ring_big > stage_big ? ring_big : stage_big) + par_big;
     constexpr size_t lds_small = (ring_small > stage_small ? ring_small : stage_small) + par_small;
