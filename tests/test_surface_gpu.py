@@ -399,9 +399,11 @@ def test_fused_driver_at_baseline_size_matches_reference(weights0, golden, name)
     # runs to it; at 95 % a perfect implementation fails one of them in more than half of all builds (any change of a summation
     # order redraws all 16), at 99 % in 15 %.  The 95 % interval and the t statistic go to the parity report (`inside_95`).
     # And the run-to-run distribution is not Gaussian: a dataset mean moves when single fits land in another basin (one such event
-    # is worth 0.1-0.4 mm on the 1015-pose mean), so the sample sd of five runs is itself unstable - the reference's own sd on draws
-    # A / b / c is 0.156 / 0.048 / 0.348 mm where the 33-member HIP ensembles have 0.166 / 0.177 / 0.190
-    # (profiles/ensemble_r05.json; F tests of b and c against the ensembles: p = 0.008 and 0.02, in opposite directions).
+    # is worth 0.1-0.4 mm on the 1015-pose mean), so the sample sd of five runs is itself unstable - the reference's own sd over five
+    # runs on draws A / b / c is 0.156 / 0.048 / 0.348 mm where the 33-member HIP ensembles have 0.166 / 0.177 / 0.190
+    # (profiles/ensemble_r05.json).  Draw b showed it: its five runs gave a 95 % half-width of 0.130 mm and the HIP run sat at 0.1315;
+    # of three more reference runs (env5-7, generated to find out which side was off) one landed 0.20 mm from the rest, the sd became
+    # 0.087 mm, the 95 % half-width 0.217 mm and the same HIP run sits at 0.10 mm from the eight-run mean.
     PI_LEVEL = 0.995
     bound, bound95, centre, tstat = {}, {}, {}, {}
     for key, hip in (("mpjpe", p1), ("pa_mpjpe", p2)):
