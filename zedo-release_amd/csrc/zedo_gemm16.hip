@@ -117,6 +117,11 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     unsigned woff0, xoff0;
     { const int g = wid * IA * 64 + lane, r = g / CPR; woff0 = (unsigned)(r * RB + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
     { const int g = wid * IB * 64 + lane, r = g / CPR; xoff0 = (unsigned)(r * RB + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
+#ifdef ZEDO_X16_NT      // A/B knob: non-temporal policy on the activation tiles.  Round 5: in the stand-alone harness (the same planes re-read by
+    constexpr bool X_NT = true;   // every launch) the residual layer gains 3 % (319 -> 309 us); in the product, where a layer's input was just
+#else                   // written by the launch before it, the hidden launch LOSES 3 % (0.310 -> 0.320 ms, A/B A/B on one box): off.
+    constexpr bool X_NT = false;
+#endif
     auto dma = [&](int kb, int slot) {
         const char *wk = Wbase + (size_t)kb * wkb, *xk = Xbase + (size_t)kb * xkb;
 #ifdef ZEDO_NO_DMA_GROUP   // A/B knob of the harness: one M0 write per piece, as until round 5
@@ -128,7 +133,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
         }
 #else
         dma16n<IA>(wk, woff0, lds0 + slot * SLOT + wid * IA * 1024);
-        if constexpr (!XF32) dma16n<IB>(xk, xoff0, lds0 + slot * SLOT + BN * RB + wid * IB * 1024);
+        if constexpr (!XF32) dma16n<IB, X_NT>(xk, xoff0, lds0 + slot * SLOT + BN * RB + wid * IB * 1024);
 #endif
     };
 
