@@ -190,7 +190,13 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     // hidden layers: waves inside the k loop outrank the co-resident workgroup's epilogue waves in the SIMD's arbitration
     // (measured 337 -> 334 us per layer; the other way round - epilogue above loop - 340 -> 345; on the thin layers nothing)
     constexpr bool LOOP_PRIO = (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) && !XF32;
-    if constexpr (LOOP_PRIO) __builtin_amdgcn_s_setprio(3);
+#ifndef ZEDO_PRIO16_LOOP
+#define ZEDO_PRIO16_LOOP 3      // A/B knobs: wave priority inside the k loop / in the epilogue of the hidden layers
+#endif
+#ifndef ZEDO_PRIO16_EPI
+#define ZEDO_PRIO16_EPI 0
+#endif
+    if constexpr (LOOP_PRIO) __builtin_amdgcn_s_setprio(ZEDO_PRIO16_LOOP);
 #pragma unroll
     for (int t = 0; t < NBUF; ++t) dma(min(t, KB - 1), t);
     if constexpr (XF32) {
@@ -242,7 +248,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();           // drain the trailing DMA before the ring becomes the epilogue stage
     TL16_MARK(tl2)
-    if constexpr (LOOP_PRIO) __builtin_amdgcn_s_setprio(0);
+    if constexpr (LOOP_PRIO) __builtin_amdgcn_s_setprio(ZEDO_PRIO16_EPI);
 
     // ---- epilogue: GroupNorm + SiLU on the accumulators, staged through the LDS row-wise (chunk c of stage row sr at
     //      position c ^ (sr & 7), as in zedo_gemm.hip), then per thread 16 consecutive channels of a row: [residual from
