@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sensitivity of the GPU parity suite: seven one-line arithmetic mutations of the HIP path, each of which must turn
+"""Sensitivity of the GPU parity suite: nine one-line arithmetic mutations of the HIP path, each of which must turn
 at least one `-m gpu` test red (run on the GPU box from the repo root: `python tools/mutation_check.py [out.txt]`).
 
 Each mutant is the product library built with ONE extra -D flag (the hooks are `#ifdef ZEDO_MUT_*` lines in csrc/,
@@ -24,6 +24,9 @@ MUTANTS = [
     # round 4: the rewritten IPO kernel and the split post_dense of small batches
     ("ZEDO_MUT_IPO_JOINT", "IPO: the 17th key joint (lane 16 of the half-wave) drops out of the gradient sums (zedo_geom.hip; opt_main.py:189-191)"),
     ("ZEDO_MUT_POST_Q3", "post_dense of batches <= 2048 rows: the fourth K quarter is read from the third (zedo_geom.hip post_reduce_kernel)"),
+    # round 5: the split-fp16 mode (every GPU test runs in both modes; these two must turn f16x3 cells red and leave f32 cells green)
+    ("ZEDO_MUT_F16_DROP_LH", "f16x3: the W_low x X_high MFMA of every k block is dropped - W as plain fp16 (zedo_gemm16.hip mma)"),
+    ("ZEDO_MUT_F16_XLOW0", "f16x3: the low pieces of the activations are lost in the first of the 64 k blocks of every dense layer (zedo_gemm16.hip)"),
 ]
 
 

@@ -164,10 +164,12 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     // product-major: consecutive MFMAs go to different accumulators; the small terms first.  The ORDER (lh, hl, hh per
     // block, blocks ascending) is the same for every tile shape: two launches of the same rows agree bit for bit.
     auto mma = [&](int set) {
+#ifndef ZEDO_MUT_F16_DROP_LH     // tools/mutation_check.py only: the low pieces of W never meet the high pieces of X (W as plain fp16)
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][i][1], fb[set][j][0], acc[i][j], 0, 0, 0);
+#endif
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -219,6 +221,12 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     }
     __syncthreads();
     fread(0, 0);
+#ifdef ZEDO_MUT_F16_XLOW0         // tools/mutation_check.py only: the low pieces of the activations are lost in the first of the 64 k blocks
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fb[0][j][1][e] = (_Float16)0.0f;
+#endif
     TL16_MARK(tl1)
     //   block kb in slot kb % NBUF, its fragments in set kb & 1:
     //       vmcnt((NBUF-2) blocks); barrier   <- every wave has read block kb (its fragments are in registers), block kb+1 has landed
