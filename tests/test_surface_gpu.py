@@ -403,7 +403,8 @@ def test_fused_driver_at_baseline_size_matches_reference(weights0, golden, name)
     # runs on draws A / b / c is 0.156 / 0.048 / 0.348 mm where the 33-member HIP ensembles have 0.166 / 0.177 / 0.190
     # (profiles/ensemble_r05.json).  Draw b showed it: its five runs gave a 95 % half-width of 0.130 mm and the HIP run sat at 0.1315;
     # of three more reference runs (env5-7, generated to find out which side was off) one landed 0.20 mm from the rest, the sd became
-    # 0.087 mm, the 95 % half-width 0.217 mm and the same HIP run sits at 0.10 mm from the eight-run mean.
+    # 0.087 mm, the 95 % half-width 0.217 mm and the same HIP run sits at 0.10 mm from the eight-run mean.  (Draws A and c got three
+    # more runs as well: sd over eight runs 0.220 / 0.087 / 0.300 mm.)
     PI_LEVEL = 0.995
     bound, bound95, centre, tstat = {}, {}, {}, {}
     for key, hip in (("mpjpe", p1), ("pa_mpjpe", p2)):
