@@ -117,9 +117,13 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     unsigned woff0, xoff0;
     { const int g = wid * IA * 64 + lane, r = g / CPR; woff0 = (unsigned)(r * RB + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
     { const int g = wid * IB * 64 + lane, r = g / CPR; xoff0 = (unsigned)(r * RB + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
-#ifdef ZEDO_X16_NT      // A/B knob: non-temporal policy on the activation tiles.  Round 5: in the stand-alone harness (the same planes re-read by
-    constexpr bool X_NT = true;   // every launch) the residual layer gains 3 % (319 -> 309 us); in the product, where a layer's input was just
-#else                   // written by the launch before it, the hidden launch LOSES 3 % (0.310 -> 0.320 ms, A/B A/B on one box): off.
+    // Cache policy of the activation tiles: default.  Non-temporal ("nt", -DZEDO_X16_NT=1) gains 3 % on the residual layer in the stand-alone
+    // harness (319 -> 309 us), where every launch re-reads the same planes, and LOSES 3 % in the product (hidden launch 0.310 -> 0.320 ms; A/B
+    // A/B on one box), where a layer's input was just written by the launch before it; on post_dense alone, which reads its input exactly
+    // once: 51.6 -> 52.7 us.  (round 5, profiles/f16x3_designs_r05.txt)
+#ifdef ZEDO_X16_NT
+    constexpr bool X_NT = ZEDO_X16_NT != 0;
+#else
     constexpr bool X_NT = false;
 #endif
     auto dma = [&](int kb, int slot) {
