@@ -111,7 +111,7 @@ void zedo_schedule_destroy(zedo_schedule_t *s);
 int zedo_schedule_read(const zedo_schedule_t *s, float *h_tbias, float *h_a, float *h_c);
 
 /* Bytes of device workspace needed by the row-batched entry points below for B rows: 8448 bytes per row
- * (rows rounded up to 128: the 128-row tiles of the split-fp16 mode read whole tiles) up to 2^20 rows; larger batches are walked in chunks of that many rows, so the
+ * (rows rounded up to 64) up to 2^20 rows; larger batches are walked in chunks of that many rows, so the
  * workspace never exceeds 8.9 GB (BASELINE configs 3/4: 3.5 M rows per GPU).  Environment (read once):
  * ZEDO_CHUNK_ROWS=<rows> overrides the chunk size (tests). */
 size_t zedo_workspace_bytes(int B);

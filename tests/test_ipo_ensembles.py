@@ -21,9 +21,6 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 DRAWS = ["driver_pw3d_full", "driver_pw3d_full_b", "driver_pw3d_full_c"]
-# what the GPU test measured for the HIP kernels in round 4 (profiles/parity_report_r04.jsonl), worst interior quantile in member sd
-HIP_R04 = {"driver_pw3d_full": dict(q_angle=5.46, q_scale=0.88, q_loss=6.19), "driver_pw3d_full_b": dict(q_angle=4.22, q_scale=0.94, q_loss=5.48),
-           "driver_pw3d_full_c": dict(q_angle=3.60, q_scale=1.57, q_loss=5.46)}
 
 
 def distance(ref, other):
@@ -46,19 +43,17 @@ def test_the_numpy_oracle_sits_in_the_same_band_as_the_kernels(name):
     assert not set(int(m) for m in orc["members"]) & set(range(1, 200))           # perturbation streams disjoint from the reference's and the kernels'
     dist = distance(ref, orc)
     rec = {"test": "ipo_end_state_distribution_oracle", "capture": name, "members_oracle": int(orc["q_loss"].shape[0]),
-           "members_ref": int(ref["q_loss"].shape[0]), **dist, "hip_round4_max_in_member_sd": HIP_R04[name],
+           "members_ref": int(ref["q_loss"].shape[0]), **dist,
            "mean_loss_px": dict(ref=float(ref["mean_loss"].mean()), oracle=float(orc["mean_loss"].mean()),
                                 diff=float(ref["mean_loss"].mean() - orc["mean_loss"].mean()))}
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "parity_report.jsonl"), "a") as f:
-        f.write(json.dumps(rec) + "\n")
+    # the record goes to the parity report only when asked for (ZEDO_PARITY_REPORT=<path>): a plain CPU pytest run leaves the tree alone;
+    # how the oracle's distance compares with the kernels' is a report (tools/parity_summary.py reads both records), not an assertion
+    # about committed fixtures
+    if os.environ.get("ZEDO_PARITY_REPORT"):
+        with open(os.environ["ZEDO_PARITY_REPORT"], "a") as f:
+            f.write(json.dumps(rec) + "\n")
     # the kernels' own bars (tests/test_ensemble_gpu.py), applied to the oracle: an independent fp32 implementation passes them too
     for k, abs_tol in (("q_angle", 1.2e-2), ("q_scale", 3e-3), ("q_loss", 3e-2)):
         assert dist[k]["max_in_member_sd"] <= 8.0 and dist[k]["max_abs_diff"] <= abs_tol, (k, dist[k])
         assert dist[k]["median_in_member_sd"] <= 1.5, (k, dist[k])
     assert abs(rec["mean_loss_px"]["diff"]) <= 3e-3
-    # ... and it is NOT closer to the reference than the kernels are by more than the draw-to-draw variation of the statistic
-    # (loss: 5.3-6.9 for the oracle, 5.5-6.2 for the kernels): the 3-7 sd are not a property of the HIP implementation
-    assert dist["q_loss"]["max_in_member_sd"] >= 3.0 and dist["q_angle"]["max_in_member_sd"] >= 3.0, dist
-    for k in ("q_angle", "q_loss"):
-        assert HIP_R04[name][k] <= dist[k]["max_in_member_sd"] + 2.5, (k, HIP_R04[name][k], dist[k])

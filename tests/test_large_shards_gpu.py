@@ -36,7 +36,7 @@ def test_large_shard_slices_are_bitwise_the_full_run(zh, weights0, N, H):
     geom = zh.reproj_prepare(uv, K, conf, conf)
     x0 = dev(cl - cl[:, 0:1])
     kl, norm = list(range(17)), N * 17 * 2
-    assert zh.workspace_bytes(B) == min(B + (-B) % 128, CHUNK) * (64 + 2048) * 4          # bounded by one chunk
+    assert zh.workspace_bytes(B) == min(B + (-B) % 64, CHUNK) * (64 + 2048) * 4          # bounded by one chunk
     R, T0 = zh.ipo_fit(x0, uv, K, kl, "z", 8.0, 0.2, 2.0, 500, norm, B)
     xi = zh.rotate_init(x0, R, N)
     x, T = xi.clone(), T0.clone()

@@ -405,19 +405,35 @@ def test_fused_driver_at_baseline_size_matches_reference(weights0, golden, name)
     # of three more reference runs (env5-7, generated to find out which side was off) one landed 0.20 mm from the rest, the sd became
     # 0.087 mm, the 95 % half-width 0.217 mm and the same HIP run sits at 0.10 mm from the eight-run mean.  (Draws A and c got three
     # more runs as well: sd over eight runs 0.220 / 0.087 / 0.300 mm.)
+    # Round 6: level, number of reference runs and a CAP are frozen here, before any HIP result is looked at:
+    #   * K is pinned per capture (REFERENCE_RUNS): nobody can add a reference run after a failure without editing this table;
+    #   * the half-width never exceeds PI_CAP_MM however noisy the reference sample is: a sub-millimetre bias of the fused driver
+    #     larger than 0.25 mm fails whatever the sample sd says;
+    #   * PA-MPJPE is held to 0.05 mm OUTRIGHT wherever the reference's own PA scatter (sample sd of its K runs) is below the bar -
+    #     all four captures today (sd 0.002-0.022 mm) - and to the capped interval only where it is not.
+    # The HARD bar of the 0.05 mm north-star is tests/test_stage_a_gpu.py (the 1000-step loop from the reference's own IPO output:
+    # dataset means within 0.05 mm outright plus per-row bounds against the float64 loop); this test is the end-to-end plausibility
+    # check on top of it, and with random-init weights it cannot exclude a bias below the reference's own 1-ulp scatter.
     PI_LEVEL = 0.995
-    bound, bound95, centre, tstat = {}, {}, {}, {}
+    PI_CAP_MM = 0.25
+    REFERENCE_RUNS = {"driver_h36m_full": 9, "driver_pw3d_full": 8, "driver_pw3d_full_b": 8, "driver_pw3d_full_c": 8}
+    assert K == REFERENCE_RUNS[name], f"{name}: {K} reference runs on disk, {REFERENCE_RUNS[name]} pinned - the sample is fixed before the HIP run is judged"
+    bound, bound95, centre, tstat, ref_sd = {}, {}, {}, {}, {}
     for key, hip in (("mpjpe", p1), ("pa_mpjpe", p2)):
         v = np.array([float(r[key]) for r in runs]) * 1e3
         centre[key] = float(v.mean())
+        ref_sd[key] = float(v.std(ddof=1))
         unit = float(v.std(ddof=1) * np.sqrt(1 + 1 / K))
-        bound[key] = max(0.05, float(stats.t.ppf(PI_LEVEL, K - 1)) * unit)
-        bound95[key] = max(0.05, float(stats.t.ppf(0.975, K - 1)) * unit)
+        bound[key] = min(PI_CAP_MM, max(0.05, float(stats.t.ppf(PI_LEVEL, K - 1)) * unit))
+        bound95[key] = min(PI_CAP_MM, max(0.05, float(stats.t.ppf(0.975, K - 1)) * unit))
+        if key == "pa_mpjpe" and ref_sd[key] < 0.05:
+            bound[key] = bound95[key] = 0.05
         rep[f"d_{key}_vs_reference_mean_mm"] = hip * 1e3 - centre[key]
         tstat[key] = (hip * 1e3 - centre[key]) / max(unit, 1e-12)
     with open("gpurun_out/parity_report.jsonl", "a") as f:
         f.write(json.dumps({"test": name + "_prediction_interval", "reference_runs": K, "reference_mean_mm": centre, "half_width_mm": bound,
-                            "half_width_95_mm": bound95, "t_statistic": tstat,
+                            "half_width_95_mm": bound95, "t_statistic": tstat, "reference_sd_mm": ref_sd,
+                            "half_width_cap_mm": PI_CAP_MM, "level": PI_LEVEL,
                             "inside_95": {k: abs(rep[f"d_{k}_vs_reference_mean_mm"]) <= bound95[k] for k in bound95},
                             "d_mpjpe_mm": rep["d_mpjpe_vs_reference_mean_mm"], "d_pa_mpjpe_mm": rep["d_pa_mpjpe_vs_reference_mean_mm"],
                             "d_vs_unperturbed_run_mm": [rep["d_mpjpe_mm"], rep["d_pa_mpjpe_mm"]]}) + "\n")

@@ -1,4 +1,5 @@
-# A/B of compile-time knobs of zedo_gemm.hip on one GPU box:  bash tools/ab_sched.sh "" "-DZEDO_PAIR_W8_RES=0" ...
+# A/B of build variants of the library on one GPU box:  bash tools/ab_sched.sh "" "-DMY_EXPERIMENT=1" ...  (the closed -D knobs of
+# rounds 1-5 - ZEDO_SCHED_*, ZEDO_PAIR_*, ZEDO_EXP_* - left the product sources in round 6; an experiment brings its own #ifdef)
 # The knobs are APPENDED to the Makefile's flags (EXTRA=...; -ffp-contract=off stays), and the product library is
 # rebuilt without any knob when the script ends, so that no differently-built .so is left in the tree.
 P='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["roofline"]["achieved"], d["roofline"]["kernel_shader_clock_ghz"], d["kernel_time_ms_sampled_avg"])'

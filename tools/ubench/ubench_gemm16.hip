@@ -44,7 +44,7 @@ int main(int argc, char **argv) {
         a.res = epi == EPI_GN_SILU_RES ? pres : nullptr; a.out = epi == EPI_GN_SILU_RES ? (void *)pres : (void *)pout; a.out_f32 = 0;
         a.K = K; a.N = N; a.Mp = M; a.ldx = a.ldo = Ma;
         long long *nul = nullptr;
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline16), &nul, sizeof(nul)));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &nul, sizeof(nul)));
         for (int r = 0; r < 100; ++r) CK(launch_layer16(a, epi, 0));
         CK(hipEventRecord(e0));
         for (int r = 0; r < 100; ++r) CK(launch_layer16(a, epi, 0));
@@ -54,7 +54,7 @@ int main(int argc, char **argv) {
                2.0 * M * N * K / ms / 1e9);
         if (dump) {
             CK(hipMemset(dtl, 0, (size_t)maxwg * 64));
-            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline16), &dtl, sizeof(dtl)));
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &dtl, sizeof(dtl)));
             CK(launch_layer16(a, epi, 0));
             CK(hipDeviceSynchronize());
             std::vector<long long> h((size_t)maxwg * 8);
@@ -95,9 +95,9 @@ int main(int argc, char **argv) {
             const double ghz = ck[1] > 0 ? (double)ck[0] / ((double)ck[1] / 100e6) / 1e9 : 0.0;
             {   // barrier waits per ROLE (compute / DMA pair / epilogue pair), summed over all waves and workgroups
                 CK(hipMemset(dtl, 0, (size_t)maxwg * 64));
-                CK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline16), &dtl, sizeof(dtl)));
+                CK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &dtl, sizeof(dtl)));
                 CK(launch_layer16_tp(b, epi, 0)); CK(hipDeviceSynchronize());
-                long long *nul2 = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline16), &nul2, sizeof(nul2)));
+                long long *nul2 = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &nul2, sizeof(nul2)));
                 std::vector<long long> h(256 * 8 * 8);
                 CK(hipMemcpy(h.data(), dtl, h.size() * 8, hipMemcpyDeviceToHost));
                 double wt[4] = {0, 0, 0, 0}, tt[4] = {0, 0, 0, 0};

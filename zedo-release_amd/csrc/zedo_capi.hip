@@ -449,9 +449,10 @@ extern "C" int zedo_schedule_read(const zedo_schedule_t *s, float *h_tbias, floa
     return ZEDO_OK;
 }
 
-// rows of the workspace buffers: the chunk's rows rounded up to 128 (the 128-row tiles of the split-fp16 ping-pong kernel read - and write -
-// whole tiles; the rows behind the batch's own padded rows are never used as results)
-static inline size_t ws_rows(int B) { return (size_t)round_up((int)std::min((size_t)B, chunk_rows_cap()), 2 * BATCH_PAD); }
+// rows of the workspace buffers: the chunk's rows rounded up to BATCH_PAD (64), the smallest row tile every layer accepts - no launch
+// touches a row behind the batch's own padded rows (the 128-row tiles of either math mode cover floor(rows / 128) * 128 rows, the
+// remainder runs on 64-row tiles)
+static inline size_t ws_rows(int B) { return (size_t)round_up((int)std::min((size_t)B, chunk_rows_cap()), BATCH_PAD); }
 
 extern "C" size_t zedo_workspace_bytes(int B) {
     if (B < 1) return 0;

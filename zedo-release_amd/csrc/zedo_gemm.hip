@@ -56,17 +56,17 @@
 #include <atomic>
 #include <cstdlib>
 
-namespace zedo {
-
-#ifdef ZEDO_UBENCH
-__device__ long long *g_timeline = nullptr;   // ubench only: 8 x int64 per workgroup {t0, t_loop, t_loop_end, t_end, hw_id, xcc_id}
-#define TL_MARK(var) long long var = 0; if (g_timeline && threadIdx.x == 0) var = wall_clock64();
+#ifdef ZEDO_UBENCH      // the harness (tools/ubench/ubench_gemm.hip) compiles this file with per-workgroup timeline marks
+#include "../../tools/ubench/zedo_tile_hooks.inc"
 #else
 #define TL_MARK(var)
+#define TL_FLUSH(t0, t1, t2)
 #endif
 
+namespace zedo {
+
 // NBUF = depth of the LDS tile ring (2 for the big tile, whose ring already fills the LDS; 3-4 for the small
-// tiles, whose iterations are shorter than the DMA latency).  NODMA = 1 (ubench ablation only).
+// tiles, whose iterations are shorter than the DMA latency).
 // BK = K depth of one LDS tile: 32 (128-byte rows) or 16 (64-byte rows: half the LDS, so that three 128x128
 // workgroups fit on a CU).
 // SCHED (instruction placement inside the K loop): bit 0 = pin every fragment read in front of the MFMA group
@@ -80,7 +80,7 @@ __device__ long long *g_timeline = nullptr;   // ubench only: 8 x int64 per work
 // combined left to right - ((q0 + q1) + q2) + q3 - the order the split launch of small batches produces (EPI_PARTIAL
 // tiles + post_reduce_kernel), so that a row's result does not depend on the launch shape.
 // out_m0: row of a.out the tile's first row is written to (== m0 except for EPI_PARTIAL tiles, which write quarter sums).
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int KSKIP = 0, int KQ = 1>
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int BK = 32, int SCHED = 0, int KSKIP = 0, int KQ = 1>
 __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, const int n0, const int out_m0) {
     constexpr int NW = WM * WN;
     constexpr int CPR = BK / 4;                         // 16-byte chunks per tile row (8 or 4)
@@ -125,7 +125,7 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
             dma16(Wbase + (size_t)kt * (BK * 4) + (size_t)p * (RPD * 4) * a.ldw, wlane,
                   lds0 + (unsigned)(((buf * BN + (wid * IA + p) * RPD) * BK) * 4));
         else
-            dma16x(Xbase + (size_t)kt * (BK * 4) + (size_t)(p - IA) * (RPD * 4) * a.ldx, xlane,
+            dma16(Xbase + (size_t)kt * (BK * 4) + (size_t)(p - IA) * (RPD * 4) * a.ldx, xlane,
                   lds0 + (unsigned)(((NBUF * BN + buf * BM + (wid * IB + (p - IA)) * RPD) * BK) * 4));
     };
     auto dma = [&](int kt, int buf) {
@@ -141,7 +141,7 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
     for (int kg = 0; kg < KG; ++kg) foff[kg] = ((2 * kg + kh) ^ fswz) * 4;
     const float *Ab0 = As + (wn * TN + li) * BK;
     const float *Bb0 = Bs + (wm * TM + li) * BK;
-    f32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ], fa2[TI], fb2[TJ], fa3[TI], fb3[TJ];   // sets 2, 3: SCHED & 8 only
+    f32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
     auto fread = [&](f32x4(&fa)[TI], f32x4(&fb)[TJ], int buf, int kg) {
 #pragma unroll
         for (int i = 0; i < TI; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(Ab0 + (buf * BN + i * 32) * BK + foff[kg]);
@@ -164,7 +164,6 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     };
-    double dummy0 = 1.0, dummy1 = 2.0;   // (NODMA & 4 ablation only)
     // one MFMA group with DMA instructions [p0, p0 + cnt) of tile `kt` (ring slot `buf`) spread between its four sub-groups
     constexpr int H1 = (IPW + 1) / 2, H2 = IPW - H1;      // issued behind the barrier / in the first group of the next iteration
     auto mma_dma = [&](const f32x4(&fa)[TI], const f32x4(&fb)[TJ], int kt, int buf, int p0, int cnt) {
@@ -181,14 +180,11 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-            if constexpr ((NODMA & 4) != 0) {   // ubench ablation: what does same-wave VALU cost next to the MFMAs?
-                asm volatile("v_pk_fma_f32 %0, %0, %0, %0\n\tv_pk_fma_f32 %1, %1, %1, %1\n\tv_pk_fma_f32 %0, %0, %0, %0\n\tv_pk_fma_f32 %1, %1, %1, %1"
-                             : "+v"(dummy0), "+v"(dummy1));
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    static_assert(!(SCHED & 2) || (H1 <= 4 && !(NODMA & 1)), "spread DMA: at most 4 instructions per MFMA group");
+    static_assert(SCHED >= 0 && SCHED <= 3, "SCHED: bit 0 = pinned reads, bit 1 = spread DMA");
+    static_assert(!(SCHED & 2) || H1 <= 4, "spread DMA: at most 4 instructions per MFMA group");
 
     //   iteration kt (tile kt in ring slot kt % NBUF; F0 = fragments (kt, kg 0) already in registers):
     //       F1 = read(kt,1); MFMA(F0);  F0 = read(kt,2); MFMA(F1);  F1 = read(kt,3); MFMA(F0)
@@ -222,27 +218,6 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
         const int kt = kt0 + buf;
         const int nxt = (buf + 1 == NBUF) ? 0 : buf + 1;
         const int prv = (buf == 0) ? NBUF - 1 : buf - 1;
-        if constexpr ((SCHED & 8) != 0) {
-            // four fragment sets: every read of tile kt is issued one MFMA group before the barrier, so the barrier
-            // waits for nothing and is followed by two groups whose operands are already in registers
-            static_assert(!(SCHED & 8) || KG == 4, "SCHED 8 needs BK = 32");
-            fread(fa1, fb1, buf, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            fread(fa2, fb2, buf, 2);
-            fread(fa3, fb3, buf, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
-            __syncthreads();
-            fread(fa0, fb0, nxt, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_dma(fa2, fb2, min(kt + NBUF, KT - 1), buf, 0, H1);
-            mma_dma(fa3, fb3, min(kt + NBUF, KT - 1), buf, H1, H2);
-            continue;
-        }
         fread(fa1, fb1, buf, 1);
         if constexpr (SCHED & 1) __builtin_amdgcn_sched_barrier(0);
         if constexpr (SCHED & 2) mma_dma(fa0, fb0, min(kt - 1 + NBUF, KT - 1), prv, H1, H2);   // second half of the tile begun behind the last barrier
@@ -257,7 +232,6 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
             mma(fa0, fb0);
         }
         const bool skip_last = KSKIP == 1 && KG == 4 && buf == NBUF - 1;   // group 3 of the last tile is all zeros (folds: buf is unrolled)
-        if constexpr (SCHED & 4) __builtin_amdgcn_sched_barrier(0);   // keep the barrier behind the whole MFMA group
         // hipcc (ROCm 7.2) emits only lgkmcnt(0) before this barrier: it does not count the outstanding LDS-DMA,
         // so wait explicitly until tile kt+1 has landed (the NBUF-2 younger tiles may stay in flight).
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * IPW) : "memory");
@@ -271,7 +245,7 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
             __builtin_amdgcn_sched_barrier(0);
             mma_dma(fa1, fb1, min(kt + NBUF, KT - 1), buf, 0, H1);
         } else {
-            if (!(NODMA & 1)) dma(min(kt + NBUF, KT - 1), buf);
+            dma(min(kt + NBUF, KT - 1), buf);
             fread(fa0, fb0, nxt, 0);
             if constexpr (SCHED & 1) __builtin_amdgcn_sched_barrier(0);
             mma(fa1, fb1);
@@ -303,15 +277,6 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // drain the trailing (unused) DMA before any wave of the workgroup may exit
     TL_MARK(tl2)
-    if constexpr ((NODMA & 2) != 0) {   // ubench ablation: no epilogue (keep the accumulators alive)
-        float keep = (float)(dummy0 + dummy1) * 0.f;
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) keep += acc[i][j][0] + acc[i][j][15];
-        if (keep == 12345.678f) a.out[0] = keep;
-        return;
-    }
 
     // ---------------- epilogue: all global traffic goes through the (now free) LDS as 1 KB wave accesses ----
     // Direct stores from the accumulator layout would be 16 bytes per lane at a 4 KB row stride: 4x the VMEM
@@ -425,22 +390,11 @@ __device__ __forceinline__ void layer_tile(const LayerArgs &a, const int m0, con
             if (j + 1 < TJ) __syncthreads();
         }
     }
-#ifdef ZEDO_UBENCH
-    if (g_timeline) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store tail of this wave
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            long long *d = g_timeline + (size_t)blockIdx.x * 8;
-            d[0] = tl0; d[1] = tl1; d[2] = tl2; d[3] = wall_clock64();
-            d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
-            d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
-        }
-    }
-#endif
+    TL_FLUSH(tl0, tl1, tl2)
 }
 
 // One tile per workgroup: block index -> tile.
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int KSKIP = 0, int KQ = 1>
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int BK = 32, int SCHED = 0, int KSKIP = 0, int KQ = 1>
 __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, const int nwg) {
     // XCD-aware, bijective block -> tile map: the hardware places block b on XCD b % 8; give every
     // XCD a contiguous range of tiles so that the column tiles of one row tile share one L2.
@@ -454,21 +408,15 @@ __device__ __forceinline__ void layer_body(const LayerArgs &a, const int bid, co
         const int tile = lid >> 2, q = lid & 3;
         b.X = a.X + (size_t)q * a.K;
         b.W = a.W + (size_t)q * a.K;
-        layer_tile<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP, 1>(b, tile * BM, 0, lid * BM);
+        layer_tile<BM, BN, WM, WN, EPI, NBUF, BK, SCHED, KSKIP, 1>(b, tile * BM, 0, lid * BM);
         return;
     }
-#if defined(ZEDO_EXP_MAP) && ZEDO_EXP_MAP == 1
-    // experiment (tools/traffic_clock_experiment.sh): the naive map - column tile = block % ncol, so with 8 column tiles
-    // every XCD owns ONE column tile of W and every row tile of X is fetched by all 8 XCDs
-    layer_tile<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP, KQ>(a, (bid / ncol) * BM, (bid % ncol) * BN, (bid / ncol) * BM);
-#else
-    layer_tile<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP, KQ>(a, (lid / ncol) * BM, (lid % ncol) * BN, (lid / ncol) * BM);
-#endif
+    layer_tile<BM, BN, WM, WN, EPI, NBUF, BK, SCHED, KSKIP, KQ>(a, (lid / ncol) * BM, (lid % ncol) * BN, (lid / ncol) * BM);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1, int KSKIP = 0, int KQ = 1>
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int BK = 32, int SCHED = 0, int WPE = 1, int KSKIP = 0, int KQ = 1>
 __global__ __launch_bounds__(WM *WN * 64, WPE) void layer_kernel(LayerArgs a) {
-    layer_body<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, KSKIP, KQ>(a, blockIdx.x, gridDim.x);
+    layer_body<BM, BN, WM, WN, EPI, NBUF, BK, SCHED, KSKIP, KQ>(a, blockIdx.x, gridDim.x);
 }
 
 // One launch, two tile shapes: workgroups [0, nbig) run 128x128 tiles on the rows that fill whole rounds of the
@@ -476,68 +424,30 @@ __global__ __launch_bounds__(WM *WN * 64, WPE) void layer_kernel(LayerArgs a) {
 // remainder rows.  Workgroups are dispatched in order, so the
 // small tiles start as CUs run out of big tiles and fill the tail of the launch instead of costing a separate,
 // latency-bound launch (40 us -> ~26 us per layer at 50 750 rows).  Both shapes of a launch use the same block size.
-#ifndef ZEDO_SCHED_BIG
-#define ZEDO_SCHED_BIG 3
-#endif
-#ifndef ZEDO_SCHED_SMALL
-#define ZEDO_SCHED_SMALL 0
-#endif
-#ifndef ZEDO_SCHED_THIN
-#define ZEDO_SCHED_THIN 3
-#endif
-constexpr int SCHED_BIG = ZEDO_SCHED_BIG, SCHED_SMALL = ZEDO_SCHED_SMALL, SCHED_THIN = ZEDO_SCHED_THIN;
+// SCHED of the tile shapes (A/B/A/B-measured in rounds 1-4, profiles/ubench_gemm_*; the alternatives lived behind -D knobs until round 5):
+// 128x128 on 32-deep K tiles: pinned reads + spread DMA; the 16-deep product tiles: pinned reads; remainder tiles: compiler's order.
+constexpr int SCHED_BIG = 3, SCHED_SMALL = 0, SCHED_THIN = 3, SCHED_BK16 = 1;
 
-// W8 = 0: 4 waves per workgroup (64x64 per wave; remainder in 64x64 tiles); W8 = 1: 8 waves (64x32 per wave, 82
-// registers, four waves per SIMD; remainder in 64x128 tiles) - measured faster for the residual epilogue, whose
-// residual DMA + wait has more co-resident waves to hide behind.
-#ifndef ZEDO_PAIR_W8_PLAIN
-#define ZEDO_PAIR_W8_PLAIN 0
-#endif
-#ifndef ZEDO_PAIR_W8_RES
-#define ZEDO_PAIR_W8_RES 1
-#endif
-#ifndef ZEDO_PLAIN_WPE
-#define ZEDO_PLAIN_WPE 2
-#endif
-// K depth of the big plain tile: 16 (64-byte LDS rows, 32 KB ring: THREE workgroups per CU, 3 waves per SIMD) measured
-// 0.5-0.9 % faster on the plain layers than 32 (two per CU) in the loop (A/B/A/B on one box, 631.7-635.3 vs 634.1-638.4 ms
-// per 200 iterations); the residual layers stay on eight-wave BK = 32 workgroups (82 registers: two per CU).
-#ifndef ZEDO_PAIR_PLAIN_BK
-#define ZEDO_PAIR_PLAIN_BK 16
-#endif
-#ifndef ZEDO_PAIR_PLAIN_SCHED
-#define ZEDO_PAIR_PLAIN_SCHED 1
-#endif
-#ifndef ZEDO_PAIR_RES_BK        // the same for the eight-wave residual tiles (74 registers at 6 waves per SIMD): 0.7 % faster
-#define ZEDO_PAIR_RES_BK 16
-#endif
-#ifndef ZEDO_PAIR_RES_SCHED
-#define ZEDO_PAIR_RES_SCHED 1
-#endif
-#ifndef ZEDO_PAIR_PLAIN_WGS     // workgroups per CU of the plain pair launch: 3; 4 (64x128 remainder tiles on the BK = 16 ring) measured equal
-#define ZEDO_PAIR_PLAIN_WGS 3
-#endif
+// W8 = 0 (plain layers): 4 waves per workgroup (64x64 per wave, THREE workgroups per CU on the 16-deep ring: 0.5-0.9 % faster than two on
+// 32-deep tiles; remainder in 64x64 tiles); W8 = 1 (residual layers): 8 waves (64x32 per wave, 74 registers, six waves per SIMD; remainder
+// in 64x128 tiles) - measured faster for the residual epilogue, whose residual DMA + wait has more co-resident waves to hide behind.
+constexpr int PAIR_BK = 16, PLAIN_WGS = 3, PLAIN_WPE = 2;
 template <int EPI, int W8>
 // (a waves-per-SIMD bound >= 2 also makes hipcc keep the accumulators in VGPRs: no v_accvgpr_read/write, -0.6 %)
-__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? (ZEDO_PAIR_RES_BK == 16 ? 6 : 4) : (ZEDO_PAIR_PLAIN_BK == 16 ? ZEDO_PAIR_PLAIN_WGS : ZEDO_PLAIN_WPE)) void layer_pair_kernel(LayerArgs big, LayerArgs small, int nbig) {
+__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 6 : PLAIN_WGS) void layer_pair_kernel(LayerArgs big, LayerArgs small, int nbig) {
     // diagnostic: the shader clock this launch really runs at (power management differs box to box and with the load)
     long long c0 = 0, w0 = 0;
-#ifdef ZEDO_NO_CLKPROBE
-    const bool probe = false;
-#else
     const bool probe = big.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
-#endif
     if (probe) { c0 = clock64(); w0 = wall_clock64(); }
     if constexpr (W8) {
-        if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 4, EPI, 2, 0, ZEDO_PAIR_RES_BK, ZEDO_PAIR_RES_BK == 16 ? ZEDO_PAIR_RES_SCHED : SCHED_BIG>(big, blockIdx.x, nbig);
-        else layer_body<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+        if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 4, EPI, 2, PAIR_BK, SCHED_BK16>(big, blockIdx.x, nbig);
+        else layer_body<64, 128, 2, 4, EPI, 2, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     } else {
-        if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 2, EPI, 2, 0, ZEDO_PAIR_PLAIN_BK, ZEDO_PAIR_PLAIN_SCHED>(big, blockIdx.x, nbig);
-        else if constexpr (ZEDO_PAIR_PLAIN_WGS == 4) layer_body<64, 128, 2, 2, EPI, 2, 0, 16, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+        if ((int)blockIdx.x < nbig) layer_body<128, 128, 2, 2, EPI, 2, PAIR_BK, SCHED_BK16>(big, blockIdx.x, nbig);
         // remainder rows on 64x64 tiles (round 4; rounds 1-3: 32x128): the same number of tiles and the same 512-MFMA chain per wave,
         // 64 + 64 instead of 32 + 128 operand rows per K tile = 16 instead of 20 LDS-DMA instructions (6 350 rows: 505.8 -> 496.3 ms
         // per pass, 50 750 rows: 3107.8 -> 3099.9 ms, A/B/A/B on one box; bit-identical)
-        else layer_body<64, 64, 2, 2, EPI, 2, 0, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
+        else layer_body<64, 64, 2, 2, EPI, 2, 32, SCHED_SMALL>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     }
     if (probe) { big.clk[0] = clock64() - c0; big.clk[1] = wall_clock64() - w0; }
 }
@@ -546,10 +456,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? (ZEDO_PAIR_RES_BK == 16 ? 6 : 
 
 template <int EPI, int W8>
 static hipError_t launch_pair(const LayerArgs &big, const LayerArgs &small, hipStream_t st) {
-    constexpr int SM = 64, SN = (W8 || ZEDO_PAIR_PLAIN_WGS == 4) ? 128 : 64;             // remainder tile rows / columns
-    constexpr int BKB = W8 ? ZEDO_PAIR_RES_BK : ZEDO_PAIR_PLAIN_BK;
-    constexpr size_t lds_big = ((size_t)2 * (128 + 128) * BKB + 3 * 128) * sizeof(float);
-    constexpr size_t lds_small = ((!W8 && ZEDO_PAIR_PLAIN_WGS == 4) ? (size_t)64 * 128 + 3 * 128 : (size_t)2 * (SM + SN) * 32 + 3 * SN) * sizeof(float);
+    constexpr int SM = 64, SN = W8 ? 128 : 64;             // remainder tile rows / columns
+    constexpr size_t lds_big = ((size_t)2 * (128 + 128) * PAIR_BK + 3 * 128) * sizeof(float);
+    constexpr size_t lds_small = ((size_t)2 * (SM + SN) * 32 + 3 * SN) * sizeof(float);
     constexpr size_t lds = lds_big > lds_small ? lds_big : lds_small;
     if (big.Mp % 128 || small.Mp % SM || big.N % 128 || big.K % 64) return hipErrorInvalidValue;
     auto kern = layer_pair_kernel<EPI, W8>;
@@ -560,13 +469,13 @@ static hipError_t launch_pair(const LayerArgs &big, const LayerArgs &small, hipS
     return hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int NODMA = 0, int BK = 32, int SCHED = 0, int WPE = 1, int KSKIP = 0, int KQ = 1>
+template <int BM, int BN, int WM, int WN, int EPI, int NBUF = 2, int BK = 32, int SCHED = 0, int WPE = 1, int KSKIP = 0, int KQ = 1>
 static hipError_t launch_cfg(const LayerArgs &a, hipStream_t st) {
     constexpr size_t ring_f = (size_t)NBUF * (BM + BN) * BK, stage_f = (size_t)WM * 32 * BN;
     constexpr size_t lds = ((ring_f > stage_f ? ring_f : stage_f) + 3 * BN) * sizeof(float);
     if (a.Mp <= 0 || a.Mp % BM || a.N % BN || a.K % (BK * NBUF * KQ)) return hipErrorInvalidValue;
     if (KSKIP && a.K != BK * NBUF) return hipErrorInvalidValue;
-    auto kern = layer_kernel<BM, BN, WM, WN, EPI, NBUF, NODMA, BK, SCHED, WPE, KSKIP, KQ>;
+    auto kern = layer_kernel<BM, BN, WM, WN, EPI, NBUF, BK, SCHED, WPE, KSKIP, KQ>;
     static std::atomic<bool> attr_done[MAX_DEVICES];      // per instantiation and per device
     if (hipError_t e = allow_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const int nwg = (a.Mp / BM) * (a.N / BN) * (EPI == EPI_PARTIAL ? 4 : 1);
@@ -594,11 +503,10 @@ static hipError_t launch_small(const LayerArgs &a, hipStream_t st) {
     // up to one tile per CU: 64x64 tiles (four waves of 32x32, the same 512-MFMA chain per wave as a 32x128 tile and the same
     // number of workgroups) stream 64 + 64 operand rows per K tile instead of 32 + 128: 16 LDS-DMA instructions instead of 20,
     // each worth ~60 matrix-pipe cycles on the issuing SIMD - 886 rows: 19.9 -> 19.3 us per layer, 99.2 -> 96.8 ms per
-    // 1000-step pass (round 4; bit-identical).  ZEDO_SMALL_TILE32: the 32x128 shape of rounds 1-3 (A/B knob).
-    static const bool tile32 = getenv("ZEDO_SMALL_TILE32") != nullptr;
-    if (!tile32 && a.Mp % 64 == 0 && (a.Mp / 64) * (a.N / 64) <= cus)
-        return launch_cfg<64, 64, 2, 2, EPI, 4, 0, 32, SCHED_THIN & 1>(a, st);
-    if (a.Mp % 32 == 0 && (a.Mp / 32) * ncol <= cus) return launch_cfg<32, 128, 1, 4, EPI, 4, 0, 32, SCHED_THIN & 1>(a, st);
+    // 1000-step pass (round 4; bit-identical).
+    if (a.Mp % 64 == 0 && (a.Mp / 64) * (a.N / 64) <= cus)
+        return launch_cfg<64, 64, 2, 2, EPI, 4, 32, SCHED_THIN & 1>(a, st);
+    if (a.Mp % 32 == 0 && (a.Mp / 32) * ncol <= cus) return launch_cfg<32, 128, 1, 4, EPI, 4, 32, SCHED_THIN & 1>(a, st);
     auto cost = [&](int bm, int slots_per_cu, double tile_us) {
         if (a.Mp % bm) return 1e30;
         const long tiles = (long)(a.Mp / bm) * ncol;
@@ -607,9 +515,9 @@ static hipError_t launch_small(const LayerArgs &a, hipStream_t st) {
     };
     const double kdepth = a.K / 1024.0;                               // tile times below are for K = 1024
     const double c32 = cost(32, 3, 14.5 * kdepth), c64 = cost(64, 3, 28.2 * kdepth), c128 = cost(128, 2, 55.1 * kdepth);
-    if (c32 <= c64 && c32 <= c128) return launch_cfg<32, 128, 1, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);
-    if (c64 <= c128) return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);
-    return launch_cfg<128, 128, 2, 2, EPI, 2, 0, 32, SCHED_BIG, ZEDO_PLAIN_WPE>(a, st);
+    if (c32 <= c64 && c32 <= c128) return launch_cfg<32, 128, 1, 4, EPI, 2, 32, SCHED_THIN>(a, st);
+    if (c64 <= c128) return launch_cfg<64, 128, 2, 4, EPI, 2, 32, SCHED_THIN>(a, st);
+    return launch_cfg<128, 128, 2, 2, EPI, 2, 32, SCHED_BIG, PLAIN_WPE>(a, st);
 }
 
 // N == 1024 or 512 (hidden / embedding width): 128x128 tiles on 16-deep K tiles, three workgroups per CU, on the rows that
@@ -622,16 +530,14 @@ static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
     // (measured at 50 750 rows: 64x128 82 us; 32x128 92 us; 128x128 91 us; 64x256 108 us)
     if (a.K <= 64) {
         // a.kzero8: the caller vouches that k >= K - 8 is zero in X and W (pre_dense: 51 real inputs)
-        if (a.K == 64 && a.kzero8) return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN, 1, 1>(a, st);
-        return launch_cfg<64, 128, 2, 4, EPI, 2, 0, 32, SCHED_THIN>(a, st);
+        if (a.K == 64 && a.kzero8) return launch_cfg<64, 128, 2, 4, EPI, 2, 32, SCHED_THIN, 1, 1>(a, st);
+        return launch_cfg<64, 128, 2, 4, EPI, 2, 32, SCHED_THIN>(a, st);
     }
-    constexpr int WG_PER_CU = (EPI == EPI_GN_SILU_RES ? ZEDO_PAIR_RES_BK : ZEDO_PAIR_PLAIN_BK) == 32 ? 2 : (EPI == EPI_GN_SILU_RES ? 3 : ZEDO_PAIR_PLAIN_WGS);
-    constexpr int W8 = (EPI == EPI_GN_SILU_RES) ? ZEDO_PAIR_W8_RES : ZEDO_PAIR_W8_PLAIN;
+    constexpr int WG_PER_CU = 3;                                          // both pair kernels: three 128x128 workgroups per CU
+    constexpr int W8 = (EPI == EPI_GN_SILU_RES) ? 1 : 0;
     const int per_round = num_cus() * WG_PER_CU * 128 / (a.N / 128);      // rows covered by one full round of 128x128 tiles
     int rows_big = (a.Mp / per_round) * per_round;
-    static const bool split_launch = getenv("ZEDO_SPLIT_REMAINDER") != nullptr;   // A/B knob: remainder as its own launch
-    static const bool no_mid_mix = getenv("ZEDO_NO_MID_MIX") != nullptr;          // A/B knob: round-3 policy below one round
-    if (rows_big == 0 && !split_launch && !no_mid_mix) {
+    if (rows_big == 0) {
         // Less than one round of resident workgroups (mid-size batches, strong-scaling shards): a single tile shape
         // quantises badly - 6 400 rows are 400 128x128 tiles on 256 CUs, i.e. two tiles on 144 CUs and one on the rest
         // (124 us where 85 would do).  Instead: 128x128 tiles on as many rows as give every CU the SAME number of them
@@ -655,18 +561,14 @@ static hipError_t launch_wide(const LayerArgs &a, hipStream_t st) {
         }
     }
     const int rows_small = a.Mp - rows_big;                       // multiple of 64 (BATCH_PAD)
-    if (rows_small > 0 && rows_big > 0 && !split_launch) {
+    if (rows_small > 0 && rows_big > 0) {
         // eight-wave workgroups bring 64-row remainder tiles along; a short remainder finishes sooner as 32-row tiles
         if (W8 && rows_small >= 1536) return launch_pair<EPI, W8>(rows_of(a, 0, rows_big), rows_of(a, rows_big, rows_small), st);
         return launch_pair<EPI, 0>(rows_of(a, 0, rows_big), rows_of(a, rows_big, rows_small), st);
     }
-    hipError_t e = hipSuccess;
-    if (rows_small > 0) e = launch_small<EPI>(rows_of(a, rows_big, rows_small), st);
-    if (e == hipSuccess && rows_big > 0) {
-        if constexpr (EPI == EPI_GN_SILU_RES && ZEDO_PAIR_W8_RES) e = launch_cfg<128, 128, 2, 4, EPI, 2, 0, 32, SCHED_BIG, 4>(rows_of(a, 0, rows_big), st);
-        else e = launch_cfg<128, 128, 2, 2, EPI, 2, 0, 32, SCHED_BIG, ZEDO_PLAIN_WPE>(rows_of(a, 0, rows_big), st);
-    }
-    return e;
+    // one shape only: whole rounds of big tiles and nothing else (the pair kernel with no small tile), or a batch below one round
+    if (rows_big > 0) return launch_pair<EPI, W8>(rows_of(a, 0, rows_big), rows_of(a, rows_big, 0), st);
+    return launch_small<EPI>(a, st);
 }
 
 hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
@@ -677,21 +579,20 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
         // POST_SPLIT_ROWS rows one workgroup per (32-row tile, quarter) + post_reduce_kernel - a 32x64 tile is a 512-MFMA
         // dependent chain on 2 of a CU's 4 SIMDs, 18.9 us whatever the batch; four 128-MFMA chains on 4x the CUs take a
         // third of that - above it the quarters are folded inside one 64x64 tile (the chip is full there).
-        static const bool no_split = getenv("ZEDO_POST_NO_SPLIT") != nullptr;      // A/B knob: the folded tile for every size
         if (epilogue != EPI_SDE && epilogue != EPI_BIAS) return hipErrorInvalidValue;
         if (a.K % (4 * 32 * 4)) return hipErrorInvalidValue;
-        if (a.Mp <= POST_SPLIT_ROWS && a.Mp % 32 == 0 && a.scratch && !no_split) {
+        if (a.Mp <= POST_SPLIT_ROWS && a.Mp % 32 == 0 && a.scratch) {
             LayerArgs p = a;
             p.K = a.K / 4; p.out = a.scratch; p.ldo = XLD;
-            if (hipError_t e = launch_cfg<32, 64, 1, 2, EPI_PARTIAL, 4, 0, 32, SCHED_THIN>(p, st); e != hipSuccess) return e;
+            if (hipError_t e = launch_cfg<32, 64, 1, 2, EPI_PARTIAL, 4, 32, SCHED_THIN>(p, st); e != hipSuccess) return e;
             const bool sde = epilogue == EPI_SDE;
             return launch_post_reduce(sde ? a.out : nullptr, a.scratch, a.bias, a.sde_a, a.sde_c, sde ? 1 : 0, sde ? nullptr : a.out,
                                       sde ? a.rp_geom : nullptr, a.rp_T, a.rp_solve, a.rp_B, a.Mp, a.rp_N, a.rp_row0, st);
         }
         const bool small = a.Mp <= 8192 && a.Mp % 32 == 0;
         switch (epilogue) {
-            case EPI_SDE: return small ? launch_cfg<32, 64, 1, 2, EPI_SDE, 4, 0, 32, SCHED_THIN, 1, 0, 4>(a, st) : launch_cfg<64, 64, 2, 2, EPI_SDE, 4, 0, 32, SCHED_THIN, 1, 0, 4>(a, st);
-            case EPI_BIAS: return small ? launch_cfg<32, 64, 1, 2, EPI_BIAS, 4, 0, 32, SCHED_THIN, 1, 0, 4>(a, st) : launch_cfg<64, 64, 2, 2, EPI_BIAS, 4, 0, 32, SCHED_THIN, 1, 0, 4>(a, st);
+            case EPI_SDE: return small ? launch_cfg<32, 64, 1, 2, EPI_SDE, 4, 32, SCHED_THIN, 1, 0, 4>(a, st) : launch_cfg<64, 64, 2, 2, EPI_SDE, 4, 32, SCHED_THIN, 1, 0, 4>(a, st);
+            case EPI_BIAS: return small ? launch_cfg<32, 64, 1, 2, EPI_BIAS, 4, 32, SCHED_THIN, 1, 0, 4>(a, st) : launch_cfg<64, 64, 2, 2, EPI_BIAS, 4, 32, SCHED_THIN, 1, 0, 4>(a, st);
         }
         return hipErrorInvalidValue;
     }
@@ -762,133 +663,8 @@ hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStr
     return e;
 }
 
-#ifdef ZEDO_UBENCH
-// ---- variant table for tools/ubench/ubench_gemm.hip ----
-constexpr int UBENCH_NVAR = 57;
-static const char *variant_name(int v) {
-    switch (v) {
-        case 0: return "product launch_layer (128x128 BK16 x3/CU + 32x128 remainder, one launch)";
-        case 1: return "128x128 4 waves (2x2)";
-        case 2: return "256x128 8 waves (4x2)";
-        case 3: return "256x256 8 waves (4x2)";
-        case 4: return "256x256 8 waves (2x4)";
-        case 5: return "64x128 8 waves (2x4), 4-deep ring";
-        case 6: return "256x256 (4x2), no in-loop DMA [ablation]";
-        case 7: return "product, GN_SILU_RES epilogue";
-        case 8: return "128x128 4 waves (2x2), GN_SILU_RES";
-        case 9: return "128x256 4 waves (1x4... 2x2 of 64x128)";
-        case 10: return "256x128 4 waves (2x2 of 128x64)";
-        case 11: return "128x128 4 waves, BK16 ring of 2 (3 WG/CU)";
-        case 12: return "128x128 4 waves, BK16 ring of 4 (2 WG/CU)";
-        case 13: return "256x128 4 waves (128x64 each), BK16 ring 2";
-        case 14: return "128x128 4 waves, BK16 ring 2, GN_SILU_RES";
-        case 15: return "256x128 4 waves, BK16 ring 2, GN_SILU_RES";
-        case 16: return "256x128 4 waves (128x64 each), BK16 ring 4";
-        case 17: return "128x128 BK32 ring 2, reads pinned (SCHED 1)";
-        case 18: return "128x128 BK32 ring 2, DMA spread (SCHED 2)";
-        case 19: return "128x128 BK32 ring 2, pinned + spread (SCHED 3)";
-        case 20: return "128x128 BK16 ring 4, reads pinned (SCHED 1)";
-        case 21: return "128x128 BK16 ring 4, pinned + spread (SCHED 3)";
-        case 22: return "128x128 BK32 ring 2, SCHED 3, GN_SILU_RES";
-        case 23: return "128x128 BK32 ring 2, SCHED 7 (barrier behind the MFMA group)";
-        case 24: return "128x128 BK32 ring 2, SCHED 7, GN_SILU_RES";
-        case 25: return "128x128 BK32 ring 2, SCHED 11 (4 fragment sets, barrier mid-stream)";
-        case 26: return "128x128 BK32 ring 2, SCHED 11, GN_SILU_RES";
-        case 27: return "128x128 SCHED 1, no in-loop DMA [ablation]";
-        case 28: return "128x128 SCHED 3, no epilogue [ablation]";
-        case 29: return "128x128 SCHED 1, no in-loop DMA, no epilogue [ablation]";
-        case 30: return "128x128 BK16 ring 2, SCHED 1, 3 waves/SIMD (3 WG/CU)";
-        case 31: return "128x128 BK16 ring 2, SCHED 1, 3 waves/SIMD, GN_SILU_RES";
-        case 32: return "128x128 BK16 ring 2, SCHED 0, 3 waves/SIMD";
-        case 33: return "128x128 BK16 ring 2, SCHED 1 (2 waves/SIMD by registers)";
-        case 34: return "128x128 8 waves (2x4: 64x32 per wave), SCHED 3, 4 waves/SIMD";
-        case 35: return "128x128 8 waves (4x2: 32x64 per wave), SCHED 3, 4 waves/SIMD";
-        case 36: return "128x128 8 waves (2x4), SCHED 3, 4 waves/SIMD, GN_SILU_RES";
-        case 37: return "256x256 8 waves (2x4), SCHED 3";
-        case 38: return "256x256 8 waves (2x4), SCHED 3, GN_SILU_RES";
-        case 39: return "128x128 8 waves (2x4), SCHED 1, 4 waves/SIMD";
-        case 40: return "128x128 4 waves, SCHED 3, launch_bounds(256, 2)";
-        case 41: return "128x128 4 waves, SCHED 3, launch_bounds(256, 2), GN_SILU_RES";
-        case 42: return "128x128 SCHED 3, lb(256,2), no epilogue, + 32 v_pk_fma per 64 MFMAs in the loop (1024 per tile) [ablation]";
-        case 43: return "128x128 SCHED 3, lb(256,2), with epilogue, + 32 v_pk_fma per 64 MFMAs in the loop [ablation]";
-        case 44: return "128x128 SCHED 3, lb(256,2), no epilogue [ablation]";
-        case 45: return "64x128 8 waves ring 2 SCHED 3 (3 WG/CU)";
-        case 46: return "64x128 8 waves ring 4 SCHED 3 (1 WG/CU)";
-        case 47: return "32x128 4 waves ring 4 SCHED 1 (1 WG/CU)";
-        case 48: return "32x128 4 waves ring 2 SCHED 3 (3 WG/CU)";
-        case 49: return "128x128 4 waves SCHED 3 lb(256,2)";
-        case 50: return "64x128 4 waves (2x2: 32x64 per wave) ring 2 SCHED 3";
-        case 51: return "= 30 (product big tile, plain) with K summed as 4 quarter chains (KQ 4)";
-        case 52: return "128x128 8 waves (2x4) BK16 SCHED 1, 6 waves/SIMD, GN_SILU_RES (product big tile, residual)";
-        case 53: return "= 52 with K summed as 4 quarter chains (KQ 4)";
-        case 54: return "64x64 4 waves ring 4 SCHED 1 (product tile up to 1 024 rows) with KQ 4";
-        case 55: return "= 51 (KQ 4) at 2 workgroups per CU (no spills)";
-        case 56: return "= 53 (KQ 4, residual) at 4 waves/SIMD (no spills)";
-    }
-    return "?";
-}
-static hipError_t launch_variant(const LayerArgs &a, int v, hipStream_t st) {
-    switch (v) {
-        case 0: return launch_layer(a, EPI_GN_SILU, st);
-        case 1: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU>(a, st);
-        case 2: return launch_cfg<256, 128, 4, 2, EPI_GN_SILU>(a, st);
-        case 3: return launch_cfg<256, 256, 4, 2, EPI_GN_SILU>(a, st);
-        case 4: return launch_cfg<256, 256, 2, 4, EPI_GN_SILU>(a, st);
-        case 5: return launch_cfg<64, 128, 2, 4, EPI_GN_SILU, 4>(a, st);
-        case 6: return launch_cfg<256, 256, 4, 2, EPI_GN_SILU, 2, 1>(a, st);
-        case 7: return launch_layer(a, EPI_GN_SILU_RES, st);
-        case 8: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES>(a, st);
-        case 9: return launch_cfg<128, 256, 2, 2, EPI_GN_SILU>(a, st);
-        case 10: return launch_cfg<256, 128, 2, 2, EPI_GN_SILU>(a, st);
-        case 11: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 16>(a, st);
-        case 12: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 4, 0, 16>(a, st);
-        case 13: return launch_cfg<256, 128, 2, 2, EPI_GN_SILU, 2, 0, 16>(a, st);
-        case 14: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 16>(a, st);
-        case 15: return launch_cfg<256, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 16>(a, st);
-        case 16: return launch_cfg<256, 128, 2, 2, EPI_GN_SILU, 4, 0, 16>(a, st);
-        case 17: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 1>(a, st);
-        case 18: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 2>(a, st);
-        case 19: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 3>(a, st);
-        case 20: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 4, 0, 16, 1>(a, st);
-        case 21: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 4, 0, 16, 3>(a, st);
-        case 22: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 32, 3>(a, st);
-        case 23: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 7>(a, st);
-        case 24: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 32, 7>(a, st);
-        case 25: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 11>(a, st);
-        case 26: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 32, 11>(a, st);
-        case 27: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 1, 32, 1>(a, st);
-        case 28: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 2, 32, 3>(a, st);
-        case 29: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 3, 32, 1>(a, st);
-        case 30: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 16, 1, 3>(a, st);
-        case 31: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 16, 1, 3>(a, st);
-        case 32: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 16, 0, 3>(a, st);
-        case 33: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 16, 1>(a, st);
-        case 34: return launch_cfg<128, 128, 2, 4, EPI_GN_SILU, 2, 0, 32, 3, 4>(a, st);
-        case 35: return launch_cfg<128, 128, 4, 2, EPI_GN_SILU, 2, 0, 32, 3, 4>(a, st);
-        case 36: return launch_cfg<128, 128, 2, 4, EPI_GN_SILU_RES, 2, 0, 32, 3, 4>(a, st);
-        case 37: return launch_cfg<256, 256, 2, 4, EPI_GN_SILU, 2, 0, 32, 3>(a, st);
-        case 38: return launch_cfg<256, 256, 2, 4, EPI_GN_SILU_RES, 2, 0, 32, 3>(a, st);
-        case 39: return launch_cfg<128, 128, 2, 4, EPI_GN_SILU, 2, 0, 32, 1, 4>(a, st);
-        case 40: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 3, 2>(a, st);
-        case 41: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU_RES, 2, 0, 32, 3, 2>(a, st);
-        case 42: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 6, 32, 3, 2>(a, st);
-        case 43: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 4, 32, 3, 2>(a, st);
-        case 44: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 2, 32, 3, 2>(a, st);
-        case 45: return launch_cfg<64, 128, 2, 4, EPI_GN_SILU, 2, 0, 32, 3>(a, st);
-        case 46: return launch_cfg<64, 128, 2, 4, EPI_GN_SILU, 4, 0, 32, 3>(a, st);
-        case 47: return launch_cfg<32, 128, 1, 4, EPI_GN_SILU, 4, 0, 32, 1>(a, st);
-        case 48: return launch_cfg<32, 128, 1, 4, EPI_GN_SILU, 2, 0, 32, 3>(a, st);
-        case 49: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 3, 2>(a, st);
-        case 50: return launch_cfg<64, 128, 2, 2, EPI_GN_SILU, 2, 0, 32, 3>(a, st);
-        case 51: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 16, 1, 3, 0, 4>(a, st);
-        case 52: return launch_cfg<128, 128, 2, 4, EPI_GN_SILU_RES, 2, 0, 16, 1, 6>(a, st);
-        case 53: return launch_cfg<128, 128, 2, 4, EPI_GN_SILU_RES, 2, 0, 16, 1, 6, 0, 4>(a, st);
-        case 54: return launch_cfg<64, 64, 2, 2, EPI_GN_SILU, 4, 0, 32, 1, 1, 0, 4>(a, st);
-        case 55: return launch_cfg<128, 128, 2, 2, EPI_GN_SILU, 2, 0, 16, 1, 2, 0, 4>(a, st);
-        case 56: return launch_cfg<128, 128, 2, 4, EPI_GN_SILU_RES, 2, 0, 16, 1, 4, 0, 4>(a, st);
-    }
-    return hipErrorInvalidValue;
-}
+#ifdef ZEDO_UBENCH      // variant table of the harness (tools/ubench/ubench_gemm.hip): not part of the library
+#include "../../tools/ubench/zedo_gemm_variants.inc"
 #endif
 
 }  // namespace zedo

@@ -38,6 +38,13 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifdef ZEDO_UBENCH      // the harness (tools/ubench/ubench_gemm16.hip) compiles this file with per-workgroup timeline marks
+#include "../../tools/ubench/zedo_tile_hooks.inc"
+#else
+#define TL_MARK(var)
+#define TL_FLUSH(t0, t1, t2)
+#endif
+
 namespace zedo {
 
 // fp32 [rows][cols] (row stride ld) * scale -> planes [cols/16][ldr][2][16] (k-block-major, zedo_tile.h)
@@ -65,12 +72,6 @@ hipError_t launch_split_planes(const float *src, int rows, int cols, int ld, flo
     return hipGetLastError();
 }
 
-#ifdef ZEDO_UBENCH
-__device__ long long *g_timeline16 = nullptr;   // ubench only: 8 x int64 per workgroup {t0, t_loop, t_loop_end, t_end, hw_id, xcc_id}
-#define TL16_MARK(var) long long var = 0; if (g_timeline16 && threadIdx.x == 0) var = wall_clock64();
-#else
-#define TL16_MARK(var)
-#endif
 
 // One BM x BN output tile.  WM x WN waves, each TM x TN = (BM/WM) x (BN/WN); ring of NBUF 16-k blocks (2 for the big tile,
 // whose co-resident workgroups cover each other's DMA latency; 4 for the small tiles, which run at the end of a launch
@@ -94,7 +95,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     extern __shared__ __attribute__((aligned(16))) char smem16[];
     float *Ps = reinterpret_cast<float *>(smem16 + BODY_B);           // [3][BN] bias | gamma | beta
 
-    TL16_MARK(tl0)
+    TL_MARK(tl0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN, li = lane & 31, kh = lane >> 5;
@@ -102,11 +103,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     // instruction reads 1 KB of memory (16 rows x 64 bytes; round 5 - with [row][k/16] rows 4 KB apart the same stream ran at 0.6x)
     const size_t wkb = (size_t)a.N * RB, xkb = (size_t)a.ldx * RB;   // bytes between k blocks of W / X
     const char *Wbase = reinterpret_cast<const char *>(a.W) + (size_t)n0 * RB;
-#ifdef ZEDO_EXP_XREUSE     // timing experiment of the harness only (wrong values): every row tile reads the first 256 rows - X always hits the L2
-    const char *Xbase = reinterpret_cast<const char *>(a.X) + (size_t)(m0 & 255) * RB;
-#else
     const char *Xbase = reinterpret_cast<const char *>(a.X) + (size_t)m0 * RB;
-#endif
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem16;
 
     // DMA instruction p of this wave moves the 16-byte chunks g = (wid * I + p) * 64 + lane of the tile's block: LDS row
@@ -117,28 +114,10 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     unsigned woff0, xoff0;
     { const int g = wid * IA * 64 + lane, r = g / CPR; woff0 = (unsigned)(r * RB + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
     { const int g = wid * IB * 64 + lane, r = g / CPR; xoff0 = (unsigned)(r * RB + (((g % CPR) ^ ((r >> 2) & 3)) * 16)); }
-    // Cache policy of the activation tiles: default.  Non-temporal ("nt", -DZEDO_X16_NT=1) gains 3 % on the residual layer in the stand-alone
-    // harness (319 -> 309 us), where every launch re-reads the same planes, and LOSES 3 % in the product (hidden launch 0.310 -> 0.320 ms; A/B
-    // A/B on one box), where a layer's input was just written by the launch before it; on post_dense alone, which reads its input exactly
-    // once: 51.6 -> 52.7 us.  (round 5, profiles/f16x3_designs_r05.txt)
-#ifdef ZEDO_X16_NT
-    constexpr bool X_NT = ZEDO_X16_NT != 0;
-#else
-    constexpr bool X_NT = false;
-#endif
     auto dma = [&](int kb, int slot) {
         const char *wk = Wbase + (size_t)kb * wkb, *xk = Xbase + (size_t)kb * xkb;
-#ifdef ZEDO_NO_DMA_GROUP   // A/B knob of the harness: one M0 write per piece, as until round 5
-#pragma unroll
-        for (int p = 0; p < IA; ++p) dma16(wk, woff0 + p * 1024, lds0 + slot * SLOT + (wid * IA + p) * 1024);
-        if constexpr (!XF32) {
-#pragma unroll
-            for (int p = 0; p < IB; ++p) dma16(xk, xoff0 + p * 1024, lds0 + slot * SLOT + BN * RB + (wid * IB + p) * 1024);
-        }
-#else
         dma16n<IA>(wk, woff0, lds0 + slot * SLOT + wid * IA * 1024);
-        if constexpr (!XF32) dma16n<IB, X_NT>(xk, xoff0, lds0 + slot * SLOT + BN * RB + wid * IB * 1024);
-#endif
+        if constexpr (!XF32) dma16n<IB>(xk, xoff0, lds0 + slot * SLOT + BN * RB + wid * IB * 1024);
     };
 
     f32x16 acc[TI][TJ];
@@ -196,13 +175,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
     // hidden layers: waves inside the k loop outrank the co-resident workgroup's epilogue waves in the SIMD's arbitration
     // (measured 337 -> 334 us per layer; the other way round - epilogue above loop - 340 -> 345; on the thin layers nothing)
     constexpr bool LOOP_PRIO = (EPI == EPI_GN_SILU || EPI == EPI_GN_SILU_RES) && !XF32;
-#ifndef ZEDO_PRIO16_LOOP
-#define ZEDO_PRIO16_LOOP 3      // A/B knobs: wave priority inside the k loop / in the epilogue of the hidden layers
-#endif
-#ifndef ZEDO_PRIO16_EPI
-#define ZEDO_PRIO16_EPI 0
-#endif
-    if constexpr (LOOP_PRIO) __builtin_amdgcn_s_setprio(ZEDO_PRIO16_LOOP);
+    if constexpr (LOOP_PRIO) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int t = 0; t < NBUF; ++t) dma(min(t, KB - 1), t);
     if constexpr (XF32) {
@@ -231,7 +204,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
 #pragma unroll
         for (int e = 0; e < 8; ++e) fb[0][j][1][e] = (_Float16)0.0f;
 #endif
-    TL16_MARK(tl1)
+    TL_MARK(tl1)
     //   block kb in slot kb % NBUF, its fragments in set kb & 1:
     //       vmcnt((NBUF-2) blocks); barrier   <- every wave has read block kb (its fragments are in registers), block kb+1 has landed
     //       DMA(block kb+NBUF -> slot of kb);  read(block kb+1) -> the other set;  MFMA(block kb)
@@ -257,10 +230,11 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
         for (int u = 0; u < U; ++u)
             if (kb0 + u < KB) step(kb0 + u, u % NBUF, u & 1);
     }
+    // even rings have no tail: K / 16 is a multiple of the ring depth - launch_layer16 refuses any other K for every instantiation
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();           // drain the trailing DMA before the ring becomes the epilogue stage
-    TL16_MARK(tl2)
-    if constexpr (LOOP_PRIO) __builtin_amdgcn_s_setprio(ZEDO_PRIO16_EPI);
+    TL_MARK(tl2)
+    if constexpr (LOOP_PRIO) __builtin_amdgcn_s_setprio(0);
 
     // ---- epilogue: GroupNorm + SiLU on the accumulators, staged through the LDS row-wise (chunk c of stage row sr at
     //      position c ^ (sr & 7), as in zedo_gemm.hip), then per thread 16 consecutive channels of a row: [residual from
@@ -454,18 +428,7 @@ __device__ __forceinline__ void layer16_tile(const Layer16Args &a, const int m0,
             if (j + 1 < TJ) __syncthreads();
         }
     }
-#ifdef ZEDO_UBENCH
-    if (g_timeline16) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store tail of this wave
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            long long *d = g_timeline16 + (size_t)blockIdx.x * 8;
-            d[0] = tl0; d[1] = tl1; d[2] = tl2; d[3] = wall_clock64();
-            d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
-            d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
-        }
-    }
-#endif
+    TL_FLUSH(tl0, tl1, tl2)
 }
 
 // block -> tile, XCD aware (the hardware places block b on XCD b % 8): every XCD gets a contiguous range of tiles so that
@@ -490,18 +453,14 @@ __device__ __forceinline__ void layer16_body(const Layer16Args &a, const int bid
 // only resident workgroup is fully exposed: not adopted; so were round 5's loader-wave and tile ping-pong designs).
 // BIG_N = 128: batches between 2 048 and 8 192 rows take 128x128 tiles (three workgroups per CU) - see launch_layer16.
 constexpr int BIG_M = 128;
-#ifndef ZEDO_BIG_NBUF16
-#define ZEDO_BIG_NBUF16 3      // ring depth of the 128 x 256 tile: 3 x 24 KB = 72 KB (the 64 KB epilogue stage fits inside), 2 workgroups per CU = 150 KB
-#endif
-#ifndef ZEDO_MID_NBUF16
-#define ZEDO_MID_NBUF16 2      // ring depth of the 128 x 128 tile (batches of 2 048 - 8 192 rows, three workgroups per CU)
-#endif
+constexpr int BIG_NBUF16 = 3;     // ring depth of the 128 x 256 tile: 3 x 24 KB = 72 KB (the 64 KB epilogue stage fits inside), 2 workgroups per CU = 150 KB
+constexpr int MID_NBUF16 = 2;     // ring depth of the 128 x 128 tile (batches of 2 048 - 8 192 rows, three workgroups per CU)
 template <int EPI, int BIG_N>
 __global__ __launch_bounds__(256, BIG_N == 256 ? 2 : 3) void layer16_pair_kernel(Layer16Args big, Layer16Args small, int nbig) {
     long long c0 = 0, w0 = 0;
     const bool probe = big.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     if (probe) { c0 = clock64(); w0 = wall_clock64(); }
-    if ((int)blockIdx.x < nbig) layer16_body<BIG_M, BIG_N, 2, 2, EPI, BIG_N == 256 ? ZEDO_BIG_NBUF16 : ZEDO_MID_NBUF16>(big, blockIdx.x, nbig);
+    if ((int)blockIdx.x < nbig) layer16_body<BIG_M, BIG_N, 2, 2, EPI, BIG_N == 256 ? BIG_NBUF16 : MID_NBUF16>(big, blockIdx.x, nbig);
     else layer16_body<64, 64, 2, 2, EPI, 4>(small, (int)blockIdx.x - nbig, (int)gridDim.x - nbig);
     if (probe) { big.clk[0] = clock64() - c0; big.clk[1] = wall_clock64() - w0; }
 }
@@ -541,7 +500,7 @@ static hipError_t launch_thin16(K kern, std::atomic<bool> *attr_done, size_t lds
 
 template <int EPI, int BIG_N>
 static hipError_t launch_pair16(const Layer16Args &big, const Layer16Args &small, hipStream_t st) {
-    constexpr size_t ring_big = (BIG_N == 256 ? ZEDO_BIG_NBUF16 : ZEDO_MID_NBUF16) * (BIG_M + BIG_N) * 64, stage_big = (size_t)64 * BIG_N * 4, par_big = 3 * BIG_N * sizeof(float);
+    constexpr size_t ring_big = (BIG_N == 256 ? BIG_NBUF16 : MID_NBUF16) * (BIG_M + BIG_N) * 64, stage_big = (size_t)64 * BIG_N * 4, par_big = 3 * BIG_N * sizeof(float);
     constexpr size_t ring_small = 4 * (64 + 64) * 64, stage_small = (size_t)64 * 64 * 4, par_small = 3 * 64 * sizeof(float);
     constexpr size_t lds_big = (ring_big > stage_big ? ring_big : stage_big) + par_big;
     constexpr size_t lds_small = (ring_small > stage_small ? ring_small : stage_small) + par_small;
@@ -565,7 +524,11 @@ static Layer16Args rows_of16(const Layer16Args &a, int row0, int rows) {
 }
 
 hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st) {
+    // K / 16 must be a multiple of the ring depth of EVERY tile the launch may pick (the prologue fills NBUF slots with blocks
+    // 0 .. NBUF - 1 and the ring slot of block kb is kb % NBUF at compile time): 4-deep rings (64x64 tiles, pre_dense) K % 64, the
+    // 8-deep ring of post_dense K % 128; the 2- and 3-deep rings of the big tiles are covered by K % 64 (3: guarded tail in the loop)
     if (a.Mp <= 0 || a.Mp % 64 || a.K % 64 || !a.W) return hipErrorInvalidValue;
+    if (a.N == XLD && a.K % (8 * 16)) return hipErrorInvalidValue;
     if ((a.X && a.ldx < a.Mp) || (a.out && !a.out_f32 && a.N != XLD && a.ldo < a.Mp)) return hipErrorInvalidValue;   // planes operands carry their row count
     if (a.Xf32) {               // pre_dense
         if (a.K != XLD || a.N % 128 || epilogue != EPI_GN_SILU || !a.out) return hipErrorInvalidValue;

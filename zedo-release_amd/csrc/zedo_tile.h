@@ -35,24 +35,6 @@ __device__ __forceinline__ float join_f16(_Float16 h, _Float16 l) { return (floa
 // VALU add per instruction inside the K loop, and VALU issue time is matrix-pipe time here.  M0 (the LDS
 // destination) is compiler-reserved: it is saved and restored inside the statement.  hipcc does not count this load
 // in its vmcnt bookkeeping - every consumer below sits behind an explicit s_waitcnt vmcnt + barrier.
-#ifdef ZEDO_EXP_XSC1   // experiment: activation (X) tiles fetched past the per-XCD L2's non-coherent lines
-#if ZEDO_EXP_XSC1 == 1
-#define ZEDO_XMOD "sc1"
-#elif ZEDO_EXP_XSC1 == 2
-#define ZEDO_XMOD "sc0 sc1"
-#else
-#define ZEDO_XMOD "nt"
-#endif
-__device__ __forceinline__ void dma16x(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 " ZEDO_XMOD "\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(sbase), "v"(voff), "s"(lds_byte_addr)
-                 : "memory");
-}
-#else
-#define dma16x dma16
-#endif
 __device__ __forceinline__ void dma16(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
@@ -65,25 +47,23 @@ __device__ __forceinline__ void dma16(const char *sbase, unsigned voff, unsigned
 // write: the instruction's 13-bit immediate offset is added to the global AND the LDS address (checked on the device by
 // tools/ubench/ubench_dma_group.hip, which also measured the burst of a 24-MFMA block: six separate dma16 cost the issuing wave
 // 39 / 31 cycles each at 1 / 2 waves per SIMD, 4 + 2 behind two M0 writes 20 / 18).
-// NT: the non-temporal cache policy ("nt": the lines are the first to leave the L2) - an experiment knob (zedo_gemm16.hip: measured, off).
-#define ZEDO_DMA16N_BODY(MOD)                                                                                                                 \
-    if constexpr (N == 4)                                                                                                                     \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1" MOD "\n\tglobal_load_lds_dwordx4 %2, %1 offset:1024" MOD "\n\t" \
-                     "global_load_lds_dwordx4 %2, %1 offset:2048" MOD "\n\tglobal_load_lds_dwordx4 %2, %1 offset:3072" MOD "\n\ts_mov_b32 m0, %0"   \
-                     : "=&s"(keep) : "s"(sbase), "v"(voff), "s"(lds_byte_addr) : "memory");                                                    \
-    else if constexpr (N == 2)                                                                                                                \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1" MOD "\n\tglobal_load_lds_dwordx4 %2, %1 offset:1024" MOD "\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep) : "s"(sbase), "v"(voff), "s"(lds_byte_addr) : "memory");                                                    \
-    else                                                                                                                                      \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1" MOD "\n\ts_mov_b32 m0, %0"               \
-                     : "=&s"(keep) : "s"(sbase), "v"(voff), "s"(lds_byte_addr) : "memory");
-template <int N, bool NT = false>
+// (The non-temporal cache policy for the activation tiles was measured in round 5 and is off: +3 % on a stand-alone layer that re-reads the
+// same planes, -3 % in the product, where a layer's input was just written by the launch before it; profiles/f16x3_designs_r05.txt.)
+template <int N>
 __device__ __forceinline__ void dma16n(const char *sbase, unsigned voff, unsigned lds_byte_addr) {
     static_assert(N == 1 || N == 2 || N == 4, "pieces per M0 write (offsets up to 3072 fit the 13-bit signed field)");
     unsigned keep;
-    if constexpr (NT) { ZEDO_DMA16N_BODY(" nt") } else { ZEDO_DMA16N_BODY("") }
+    if constexpr (N == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\tglobal_load_lds_dwordx4 %2, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %2, %1 offset:2048\n\tglobal_load_lds_dwordx4 %2, %1 offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(sbase), "v"(voff), "s"(lds_byte_addr) : "memory");
+    else if constexpr (N == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\tglobal_load_lds_dwordx4 %2, %1 offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(sbase), "v"(voff), "s"(lds_byte_addr) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(sbase), "v"(voff), "s"(lds_byte_addr) : "memory");
 }
-#undef ZEDO_DMA16N_BODY
 
 __device__ __forceinline__ float silu_fast(float y) {
     // y * sigmoid(y) with hardware exp2 / rcp (each <= 1 ulp): |rel err| <= ~3e-7

@@ -43,14 +43,22 @@ def hypothesis_min(preds, gt_centred, protocol2, valid_ind=None, row_offset=0, d
 
 def valid_rows_mask(valid_ind, N, row_offset, B, device):
     """bool [B] on `device`: row g = row_offset + i (g = h*N + n) is True when hypothesis h is listed in valid_ind[n].
-    One flat index list built on the host (no per-pose Python statement: the full H36M test set has 567 040 poses) and
-    ONE scatter on the device.  The container contract is the reference's own - `valid_ind[idx]` supports `in` / iteration
+    One flat index list built on the host (one fetch of valid_ind[n] per pose - none at all for a rectangular integer array: the
+    full H36M test set has 567 040 poses) and ONE scatter on the device.  The container contract is the reference's own - `valid_ind[idx]` supports `in` / iteration
     (h36m.py:400 `sec_idx not in valid_ind[idx]`) - so a list, a tuple, an array of lists or a mapping {pose index: [...]}
     all work: the entries are fetched BY INDEX 0 .. N-1, never by iterating the container itself."""
     import itertools
-    per_pose = [valid_ind[n] if isinstance(valid_ind[n], (list, tuple, np.ndarray)) else list(valid_ind[n]) for n in range(N)]
-    lens = np.fromiter((len(v) for v in per_pose), dtype=np.int64, count=N)
-    h = np.fromiter(itertools.chain.from_iterable(per_pose), dtype=np.int64, count=int(lens.sum()))
+    if isinstance(valid_ind, np.ndarray) and valid_ind.dtype != object and valid_ind.ndim == 2 and valid_ind.shape[0] >= N:
+        # fast path: a rectangular array [N][m] of hypothesis indices - no Python statement per pose at all
+        h = valid_ind[:N].astype(np.int64).reshape(-1)
+        lens = np.full((N,), valid_ind.shape[1], dtype=np.int64)
+    else:
+        def entry(n):                       # each valid_ind[n] is fetched exactly once
+            v = valid_ind[n]
+            return v if isinstance(v, (list, tuple, np.ndarray)) else list(v)
+        per_pose = [entry(n) for n in range(N)]
+        lens = np.fromiter((len(v) for v in per_pose), dtype=np.int64, count=N)
+        h = np.fromiter(itertools.chain.from_iterable(per_pose), dtype=np.int64, count=int(lens.sum()))
     g = h * N + np.repeat(np.arange(N, dtype=np.int64), lens) - int(row_offset)
     g = g[(h >= 0) & (g >= 0) & (g < B)]
     ok = torch.zeros((B,), dtype=torch.bool, device=device)
