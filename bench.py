@@ -19,6 +19,14 @@ Launch forms (both give ONE JSON line from rank 0 with n_gpus = rccl_ranks = num
            4 configs[4]: run.inference without --eval on 100 000 detections x H=50: no selection, the one exchange is
              the all-gather of every hypothesis of every pose (weak: 12 500 poses per GPU).
 
+Every run with a process group (--gpus N > 1, or ZEDO_FORCE_DIST=1) additionally
+  * checks itself before anything is timed (multi_rank_selfcheck): a fixed small problem sharded over the live ranks through BOTH exchange
+    steps of the path - the P1/P2 MIN selection and the all-gather of run.inference - against the unsharded run on rank 0, whatever the
+    workload; a mismatch of either ends every rank with exit code 4;
+  * (workload 2) adds a `strong` object beside the weak-scaling headline: BASELINE configs[2]'s 1015 poses x H=50 as ONE fixed problem,
+    on rank 0 alone and split over all N ranks, timed back to back (--strong-steps passes each, both math modes): speed-up, efficiency,
+    the projection from one-GPU shard measurements (profiles/strong_shards_r*.jsonl) and bit-identity of the two selections.
+
 The JSON line also carries
   roofline     : the dominant kernel (the four 1024x1024 fp32-MFMA dense layers): algorithmic FLOP per launch
                  / its average launch duration, measured live with sampled HIP events on the launch stream;
@@ -155,7 +163,7 @@ def f16x3_tile_split(rows_launch, cus=256):
     return [(128, 256, big), (64, 64, mp - big)]
 
 
-def roofline_f16x3(h2, rows_launch):
+def roofline_f16x3(h2, rows_launch, box16=None):
     """Roofline object of the split-fp16 hidden layer: three fp16 MFMAs (al.bh + ah.bl + ah.bh) per fp32 product block:
     ISSUED flop against the dense fp16 peak, plus the bytes the tiles pull through LDS-DMA against what that path
     sustains (the binding resource).  The tile model follows the launch's own shape choice (f16x3_tile_split)."""
@@ -172,6 +180,11 @@ def roofline_f16x3(h2, rows_launch):
                 avg_launch_ms=round(h2["avg_ms"], 4), sampled_launches=h2["samples"], launches=h2["launches"],
                 kernel_shader_clock_ghz=round(ghz, 3) if ghz else None,
                 frac_at_kernel_clock=(round(issued / t / 1e12 / (2500.0 * ghz / 2.4), 4) if ghz else None),
+                # the attainable ceiling: a bare v_mfma_f32_32x32x16_f16 stream on THIS box, measured right after the timed region
+                # (zedo_probe_mfma_peak_f16: two waves per SIMD, no LDS / memory traffic) and the clock power management granted it
+                box_f16_mfma_peak_measured=(round(box16[0], 1) if box16 else None),
+                box_f16_shader_clock_ghz=(round(box16[1], 3) if box16 else None),
+                frac_of_box_peak=(round(issued / t / 1e12 / box16[0], 4) if box16 else None),
                 lds_dma_bytes_per_launch=int(dma_bytes), lds_dma_tb_per_s=round(dma_bytes / t / 1e12, 2),
                 lds_dma_sustained_tb_per_s=(round(16.0 * 256 * ghz * 1e9 / 1e12, 2) if ghz else None),
                 vmem_model_ms=round(((rows_launch / 32) * 32 * 64 * 3 * 32 + dma_bytes / 1024 * 65 + rows_launch * 4096 / 1024 * 187)
@@ -191,6 +204,66 @@ def f16x3_traffic(rows_launch):
         return None
     tj = json.load(open(tp))
     return tj.get("hidden_dense_bytes_per_launch") if int(tj.get("rows_launch", -1)) == int(rows_launch) else None
+
+
+HBM_ACHIEVABLE_GBS = 6300.0        # MI355X_MICROARCH.md: what a streaming kernel sustains of the 8 TB/s HBM3E peak
+
+
+def geometry_kernels(zh, dev, sizes=((N_POSES, N_HYPO), (70880, N_HYPO)), reps=5):
+    """the HBM / latency-bound kernels of the path - IPO, the stand-alone reprojection correction (the same reproj_row the
+    post_dense epilogue fuses), rotate_init, row_error + pose_min (P1, and P2 with its fp64 Jacobi SVD) - timed on their own with events
+    on the launch stream, at BASELINE configs[2]'s 50 750 rows and at configs[3]'s per-GPU shard of 3 544 000 rows: microseconds,
+    algorithmic bytes (every operand the kernel addresses, counted once: per-row state + per-pose constants), GB/s and the fraction of
+    the 6.3 TB/s a streaming kernel sustains.  IPO and P2 are arithmetic-bound (500 Adam iterations in registers; an fp64 3x3 SVD per
+    row): their GB/s say how far from the HBM roof the arithmetic keeps them, not how well they stream."""
+    from lib.dataset import synthetic as syn
+    out = {}
+    for N, H in sizes:
+        B = N * H
+        d = syn.make_poses(N, seed=11)
+        cl = syn.make_clusters(H, seed=11)
+        t = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+        x0 = t(cl - cl[:, 0:1])
+        uv, K, conf = t(d["db_2d"][:, :, :2]), t(d["camera_param"]), t(d["db_2d"][:, :, 2])
+        geom = zh.reproj_prepare(uv, K, conf)
+        gt = t((d["db_3d"] - d["db_3d"][:, 0:1]).astype(np.float64), torch.float64)
+        kl17, kl3 = list(range(17)), [0, 1, 4]
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            ms = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = fn()
+                e1.record()
+                e1.synchronize()
+                ms.append(e0.elapsed_time(e1))
+            return float(np.median(ms)), r
+
+        rec = {}
+
+        def put(name, ms, nbytes, bound):
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            rec[name] = dict(us=round(ms * 1e3, 1), bytes=int(nbytes), gb_per_s=round(gbs, 1), frac_of_6p3_tb_s=round(gbs / HBM_ACHIEVABLE_GBS, 4), bound=bound)
+
+        ms, (R, T) = timed(lambda: zh.ipo_fit(x0, uv, K, kl17, "z", 8.0, 0.2, 2.0, 500, N * 17 * 2, B))
+        put("ipo_17_joints_500_it", ms, B * (17 * 20 + 44 + 48), "VALU issue / latency: 500 Adam iterations x 17 joints in registers, ~0.25 MFLOP per row")
+        ms, _ = timed(lambda: zh.ipo_fit(x0, uv, K, kl3, "z", 3.0, 0.5, 2.0, 500, N * 3 * 2, B))
+        put("ipo_3_joints_500_it", ms, B * (3 * 20 + 44 + 48), "VALU issue / latency")
+        ms, x = timed(lambda: zh.rotate_init(x0, R, N))
+        put("rotate_init", ms, B * (36 + 204) + H * 204, "HBM (reads R, writes the pose rows)")
+        Tc = T.clone()
+        ms, _ = timed(lambda: zh.reproj_grad(x, geom, Tc, True))
+        put("reprojection_least_squares_T", ms, B * (204 + 12 + 204 + 12) + N * 544, "HBM (pose rows in and out; per-pose rays from the L2)")
+        ms, _ = timed(lambda: zh.min_mpjpe(x, gt, N, False))
+        put("row_error_pose_min_P1", ms, B * (204 + 8 + 8) + N * (408 + 12), "HBM")
+        ms, _ = timed(lambda: zh.min_mpjpe(x, gt, N, True))
+        put("row_error_pose_min_P2_procrustes", ms, B * (204 + 8 + 8) + N * (408 + 12), "fp64 arithmetic: one 3x3 Jacobi SVD per row")
+        out[f"{B}_rows"] = rec
+        del x, R, T, Tc, geom
+    return out
 
 
 def selection_digest(out):
@@ -302,33 +375,38 @@ SELFCHECK = dict(poses=64, hypo=5, oil=20)     # the fixed small problem of mult
 
 
 def multi_rank_selfcheck(zp, dist, weights, wl, dev, rank, world):
-    """Before anything is timed: does the N-rank result equal the one-rank result, bit for bit, on THIS transport?
-    The reference is one GPU running its hypotheses one after the other (run/opt_main.py:166, 224-228); sharding rows over
-    ranks is this repository's addition, and `bench.py --gpus N` under the driver is the only place a process group with more
-    than one RCCL member ever runs - so the run checks itself.  A fixed small problem (64 poses x 5 hypotheses x 20 steps, the
-    workload's own settings, selection or gather) is processed (a) sharded over the ranks of the live process group, through
-    the very exchange step that is about to be timed, and (b) unsharded on rank 0 with no collective at all; both digests
-    travel in the JSON line and a mismatch makes EVERY rank exit with code 4 before the timed region.
-    ZEDO_BENCH_CORRUPT_RANK=k (test hook): rank k adds 1e-3 m to its shard before the exchange."""
+    """Before anything is timed: does the N-rank result equal the one-rank result, bit for bit, on THIS transport - for BOTH
+    exchange steps of the path, whatever the workload: the P1 / P2 MIN selection (run/opt_main.py:224-228: two all-reduces per
+    protocol) and the all-gather of every hypothesis of every pose (run/inference.py:233-236)?
+    The reference is one GPU running its hypotheses one after the other (run/opt_main.py:166); sharding rows over ranks is this
+    repository's addition, and `bench.py --gpus N` under the driver is the only place a process group with more than one RCCL
+    member ever runs - so the run checks itself.  A fixed small problem (64 poses x 5 hypotheses x 20 steps, the workload's own
+    settings) is processed (a) sharded over the ranks of the live process group, through the very exchange steps, and (b) unsharded
+    on rank 0 with no collective at all; the digests of both kinds travel in the JSON line and a mismatch of EITHER makes every rank
+    exit with code 4 before the timed region.
+    ZEDO_BENCH_CORRUPT_RANK=k (test hook): rank k adds 1e-3 m to its shard before the exchange; ZEDO_BENCH_CORRUPT_KIND=selection|gather
+    restricts the corruption to one of the two checks (default: both)."""
     import hashlib
     from zedo_hip.pipeline import Pipeline, ZeDOConfig, gather_row_shards, reduce_min_over_ranks, shard_rows
     from lib.dataset import synthetic as syn
     N, H, S = SELFCHECK["poses"], SELFCHECK["hypo"], SELFCHECK["oil"]
     h36m = wl["settings"] == "h36m"
-    d = syn.make_poses(N, seed=77, dtype3d=np.float64 if (h36m and wl["select"] == "h36m") else np.float32)
+    mm_gt = h36m and wl["select"] == "h36m"
+    d = syn.make_poses(N, seed=77, dtype3d=np.float64 if mm_gt else np.float32)
     cfg = (ZeDOConfig.h36m if h36m else ZeDOConfig.pw3d)(OIL_iterations=S)
     pipe = Pipeline(weights, cfg, dev).load(syn.make_clusters(H, seed=77), d["db_2d"], d["camera_param"])
-    if wl["select"] == "h36m":
+    if mm_gt:
         mm = d["db_3d"] * 1000.0
         gt = (mm - mm[:, 0:1]) / 1000.0
     else:
         gt = (d["db_3d"] - d["db_3d"][:, 0:1]).astype(np.float64)
     gt_dev = torch.tensor(gt, dtype=torch.float64, device=dev)
     corrupt = os.environ.get("ZEDO_BENCH_CORRUPT_RANK")
+    corrupt_kind = os.environ.get("ZEDO_BENCH_CORRUPT_KIND")
 
-    def digest(x, lo, exchange):
+    def digest(kind, x, lo, exchange):
         h = hashlib.sha256()
-        if wl["select"] == "gather":
+        if kind == "gather":
             res = gather_row_shards(x, H * N) if exchange else x
             h.update(res.cpu().numpy().tobytes())
         else:
@@ -341,28 +419,32 @@ def multi_rank_selfcheck(zp, dist, weights, wl, dev, rank, world):
 
     lo, rows = shard_rows(H * N, rank, world)
     x, _ = pipe.run(row_offset=lo, rows=rows)
-    if corrupt is not None and rank == int(corrupt):
-        x = x + 1e-3
-    sharded = digest(x, lo, True)
-    whole = None
-    bad = 0
-    if rank == 0:
-        xw, _ = pipe.run()
-        whole = digest(xw, 0, False)
-        bad = int(whole != sharded)
+    xw = pipe.run()[0] if rank == 0 else None
+    out, bad = {}, 0
+    what = {"selection": "P1/P2 MIN exchange (two all-reduces per protocol)", "gather": "all-gather of every hypothesis of every pose"}
+    for kind in ("selection", "gather"):
+        xs = x + 1e-3 if (corrupt is not None and rank == int(corrupt) and corrupt_kind in (None, "", kind)) else x
+        sharded = digest(kind, xs, lo, True)
+        whole = digest(kind, xw, 0, False) if rank == 0 else None
+        if rank == 0 and whole != sharded:
+            bad |= 1 if kind == "selection" else 2
+        out[kind] = dict(sha=sharded, sha_unsharded=whole, exchange=what[kind])
     flag = torch.tensor([bad], dtype=torch.int64, device=dev)
     zp.all_reduce(flag, dist.ReduceOp.MAX)
-    ok = int(flag.item()) == 0
-    return dict(ok=ok, sha=sharded, sha_unsharded=whole, backend=dist.get_backend(), ranks=world,
-                problem=f"{N} poses x {H} hypotheses x {S} steps, {wl['settings']} settings, "
-                        f"{'all-gather' if wl['select'] == 'gather' else 'P1/P2 MIN exchange'}; rows sharded {world}-way vs unsharded on rank 0")
+    bad = int(flag.item())
+    out["selection"]["ok"], out["gather"]["ok"] = not (bad & 1), not (bad & 2)
+    return dict(ok=bad == 0, backend=dist.get_backend(), ranks=world, **out,
+                problem=f"{N} poses x {H} hypotheses x {S} steps, {wl['settings']} settings; rows sharded {world}-way vs unsharded on rank 0")
+
+
+STRONG_SHARD_FILES = ("strong_shards_r06.jsonl", "strong_shards_r04.jsonl")      # newest first
 
 
 def strong_projection(rows_per_rank, math):
-    """What ONE GPU measured for a shard of this many rows of workload 2 (profiles/strong_shards_r04.jsonl: bench.py --poses ...
-    on one MI355X) -> pass time in ms, or None when no shard within 2 % of this size was measured."""
-    tp = os.path.join(ROOT, "profiles", "strong_shards_r04.jsonl")
-    if not os.path.exists(tp):
+    """What ONE GPU measured for a shard of this many rows of workload 2 (profiles/strong_shards_r*.jsonl: bench.py --poses ...
+    on one MI355X) -> (rows, pass time in ms, file), or None when no shard within 2 % of this size was measured."""
+    tp = next((q for q in (os.path.join(ROOT, "profiles", f) for f in STRONG_SHARD_FILES) if os.path.exists(q)), None)
+    if tp is None:
         return None
     best = None
     for l in open(tp):
@@ -375,7 +457,7 @@ def strong_projection(rows_per_rank, math):
             continue
         ms = j["ms_per_step"] if j.get("math") == math else (j.get("alt_mode") or {}).get("ms_per_step")
         if ms and (best is None or abs(r - rows_per_rank) < abs(best[0] - rows_per_rank)):
-            best = (r, float(ms))
+            best = (r, float(ms), os.path.relpath(tp, ROOT))
     return best
 
 
@@ -395,6 +477,12 @@ def main():
                     help="arithmetic of the hidden layers for the HEADLINE numbers (default: exact fp32 MFMA)")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the second timed run in the other math mode (alt_mode object)")
     ap.add_argument("--dry-launch", action="store_true", help="print the rank environments the launcher would start, and exit")
+    ap.add_argument("--strong-poses", type=int, default=N_POSES,
+                    help="poses of the fixed problem of the `strong` object (multi-rank runs of workload 2; default BASELINE configs[2]'s 1015)")
+    ap.add_argument("--strong-steps", type=int, default=3, help="timed passes of the `strong` object (each also run by rank 0 alone)")
+    ap.add_argument("--no-strong", action="store_true", help="multi-rank runs: skip the `strong` object")
+    ap.add_argument("--no-geometry", action="store_true", help="skip the geometry_kernels object (one-GPU runs: IPO / reprojection / selection "
+                                                                 "kernels timed on their own at 50 750 and 3 544 000 rows)")
     a = ap.parse_args()
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -452,8 +540,11 @@ def main():
         selfcheck = multi_rank_selfcheck(zp, dist, weights, wl, dev, rank, world)
         if not selfcheck["ok"]:
             if rank == 0:
-                print(f"bench.py: multi_rank_selfcheck FAILED - {world} ranks over {selfcheck['backend']} give {selfcheck['sha']}, "
-                      f"one rank gives {selfcheck['sha_unsharded']} ({selfcheck['problem']})", file=sys.stderr, flush=True)
+                for kind in ("selection", "gather"):
+                    if not selfcheck[kind]["ok"]:
+                        print(f"bench.py: multi_rank_selfcheck FAILED ({kind}) - {world} ranks over {selfcheck['backend']} give "
+                              f"{selfcheck[kind]['sha']}, one rank gives {selfcheck[kind]['sha_unsharded']} ({selfcheck['problem']})",
+                              file=sys.stderr, flush=True)
             sys.exit(4)
 
     def one_pass():
@@ -502,6 +593,69 @@ def main():
             dt = float(tt.item())
         return dt, prof, x, out, per_rank
 
+    def strong_run(math):
+        """The `strong` object of a multi-rank run: ONE fixed problem - BASELINE configs[2]'s 1015 poses x H hypotheses - (a) on rank 0
+        alone, no collective (what the reference's single GPU does, run/opt_main.py:166), and (b) with its H*N rows split over all ranks
+        + the MIN exchange; both timed here, back to back, so that speed-up and efficiency are measured inside one run, next to the
+        projection from one-GPU shard measurements.  The two selections must agree bit for bit (exit code 4 otherwise)."""
+        Ns, K = a.strong_poses, max(1, a.strong_steps)
+        ds = syn.make_poses(Ns, seed=2024)
+        cfg_s = ZeDOConfig.pw3d(OIL_iterations=S)
+        pipe.weights.set_math(math)
+        ps = Pipeline(pipe.weights, cfg_s, dev).load(clusters, ds["db_2d"], ds["camera_param"])
+        gts = torch.tensor((ds["db_3d"] - ds["db_3d"][:, 0:1]).astype(np.float64), dtype=torch.float64, device=dev)
+        lo_s, rows_s = shard_rows(H * Ns, rank, world)
+
+        def sharded():
+            xs, _ = ps.run(row_offset=lo_s, rows=rows_s)
+            return {k: reduce_min_over_ranks(b, i) for k, (b, i) in ps.select(xs, gts, row_offset=lo_s).items()}
+
+        def alone():
+            xs, _ = ps.run()
+            return ps.select(xs, gts)
+
+        t_one, sha_one = 0.0, None
+        fence()
+        if rank == 0:                      # the other ranks wait in the fence below
+            alone()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                o1 = alone()
+            torch.cuda.synchronize()
+            t_one = (time.perf_counter() - t0) / K
+            sha_one = selection_digest(o1)
+        sharded()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            oN = sharded()
+        fence()
+        mine = time.perf_counter() - t0
+        allt = torch.empty((world,), dtype=torch.float64, device=dev)
+        zp.all_gather_into_tensor(allt, torch.tensor([mine], dtype=torch.float64, device=dev))
+        per = [float(v) / K for v in allt.cpu().tolist()]
+        t_n = max(per)
+        sha_n = selection_digest(oN)
+        bad = torch.tensor([int(rank == 0 and sha_one != sha_n)], dtype=torch.int64, device=dev)
+        zp.all_reduce(bad, dist.ReduceOp.MAX)
+        pipe.weights.set_math(a.math)
+        res = dict(math=math, scaling="strong", n_gpus=world, steps=K,
+                   workload=f"BASELINE configs[2]'s shape, {Ns} poses x H={H} x {S} OIL steps in total: rows split over {world} rank(s) + P1/P2 MIN exchange, "
+                            "against the same problem on rank 0 alone (no collective), timed back to back in this run",
+                   rows_per_gpu=rows_s, value=round(Ns / t_n, 3), unit="poses/s", ms_per_step=round(t_n * 1e3, 2),
+                   one_rank=dict(value=round(Ns / t_one, 3) if t_one else None, ms_per_step=round(t_one * 1e3, 2)),
+                   speedup_vs_one_rank=round(t_one / t_n, 3) if t_one else None,
+                   efficiency=round(t_one / t_n / world, 4) if t_one else None,
+                   selection_sha16=sha_n, one_rank_selection_sha16=sha_one, matches_one_rank=int(bad.item()) == 0,
+                   rank_pass_s=dict(min=round(min(per), 5), max=round(max(per), 5), all=[round(v, 5) for v in per]))
+        proj = strong_projection(rows_s, math) if (Ns == N_POSES and S == S_OIL and H == N_HYPO) else None
+        res["efficiency_vs_projection"] = (dict(projected_ms_per_step=proj[1], projected_rows_per_rank=proj[0], measured_ms_per_step=round(t_n * 1e3, 2),
+                                                efficiency=round(proj[1] / (t_n * 1e3), 4),
+                                                source=f"profiles/{os.path.basename(proj[2])} (one MI355X running the shard of one rank, no communication)")
+                                           if proj else None)
+        return res
+
     dt, prof, x, out, per_rank = timed_run()
     # the other arithmetic mode of the hidden layers on the same problem (reported as alt_mode, never as `value`)
     alt = None
@@ -512,9 +666,22 @@ def main():
         pipe.weights.set_math(a.math)
         alt = dict(math=alt_math, dt=dt2, prof=prof2, out=out2)
 
-    box_tf = box_ghz = None
+    # multi-rank runs of workload 2: the fixed-problem (strong-scaling) object beside the weak-scaling headline
+    strong = None
+    if use_dist and a.workload == 2 and not a.no_strong:
+        strong = strong_run(a.math)
+        if not a.no_alt_mode:
+            strong["alt_mode"] = strong_run("f16x3" if a.math == "f32" else "f32")
+        if not (strong["matches_one_rank"] and (strong.get("alt_mode") or strong)["matches_one_rank"]):
+            if rank == 0:
+                print(f"bench.py: strong object - {world} ranks give {strong['selection_sha16']}, rank 0 alone gives "
+                      f"{strong['one_rank_selection_sha16']} on the same problem", file=sys.stderr, flush=True)
+            sys.exit(4)
+
+    box_tf = box_ghz = box16 = None
     if rank == 0:
         box_tf, box_ghz = zh.probe_mfma_peak(200000)      # ~0.2 s, outside the timed region
+        box16 = zh.probe_mfma_peak_f16(1000000)           # ~0.5 s of bare fp16 MFMAs: long enough for power management to settle
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         poses_per_s = N_total * a.steps / dt
@@ -537,7 +704,7 @@ def main():
                 mfma_busy = {k: round(v["mfma_util"], 4) for k, v in tj.get("kernels", {}).items()
                              if k.startswith("layer_pair_kernel") and "mfma_util" in v} or None
             if a.math == "f16x3":
-                roof = roofline_f16x3(hid, rows_launch)
+                roof = roofline_f16x3(hid, rows_launch, box16)
             else:
               roof = dict(bound="mfma", kernel="zedo::layer_pair_kernel<{GN_SILU|GN_SILU_RES}> (128x128 tiles on 16-deep K tiles, 3 workgroups per CU, + 64x64 / 64x128 remainder tiles in the same launch): "
                                              "one 1024x1024 dense layer + GroupNorm + SiLU [+ residual] over all rows",
@@ -609,6 +776,8 @@ def main():
             "wall_ms_per_oil_step": round(dt * 1e3 / (a.steps * S), 5),
             # N ranks == 1 rank, bit for bit, on the live transport, checked before the timed region (None without a process group)
             "multi_rank_selfcheck": selfcheck,
+            # multi-rank runs of workload 2: one fixed problem (configs[2]) on rank 0 alone vs split over all ranks, timed back to back
+            "strong": strong,
             # each rank's own seconds per pass between the fences (value / ms_per_step use the maximum)
             "rank_pass_s": {"min": round(min(per_rank) / a.steps, 5), "max": round(max(per_rank) / a.steps, 5),
                             "argmin": int(np.argmin(per_rank)), "argmax": int(np.argmax(per_rank)),
@@ -619,7 +788,7 @@ def main():
             proj = strong_projection(rows, a.math)
             line["efficiency_vs_projection"] = (dict(projected_ms_per_step=proj[1], projected_rows_per_rank=proj[0],
                                                      measured_ms_per_step=round(ms_per_step, 2), efficiency=round(proj[1] / ms_per_step, 4),
-                                                     source="profiles/strong_shards_r04.jsonl (one MI355X running the shard of one rank)")
+                                                     source=f"{proj[2]} (one MI355X running the shard of one rank)")
                                                 if proj else None)
         if alt is not None:
             h2 = alt["prof"]["hidden_dense"]
@@ -635,7 +804,7 @@ def main():
                   "selection_sha16": selection_digest(alt["out"]),
                   "kernel_time_ms_sampled_avg": {k: (round(v["avg_ms"], 4) if v["avg_ms"] else None) for k, v in alt["prof"].items()}}
             if h2["avg_ms"] and alt["math"] == "f16x3":
-                am["roofline"] = roofline_f16x3(h2, rows_launch)
+                am["roofline"] = roofline_f16x3(h2, rows_launch, box16)
             elif h2["avg_ms"]:
                 am["roofline"] = dict(bound="mfma", achieved=round(2.0 * rows_launch * 1024 * 1024 / (h2["avg_ms"] * 1e-3) / 1e12, 2),
                                       peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", avg_launch_ms=round(h2["avg_ms"], 4),
@@ -643,6 +812,8 @@ def main():
             line["alt_mode"] = am
         else:
             line["alt_mode"] = None
+        # GB/s of the HBM / latency-bound kernels, at configs[2]'s rows and at configs[3]'s per-GPU shard
+        line["geometry_kernels"] = geometry_kernels(zh, dev) if (world == 1 and not a.no_geometry) else None
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights, None, 2024)
         else:

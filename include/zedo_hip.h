@@ -38,8 +38,8 @@
 extern "C" {
 #endif
 
-#define ZEDO_ABI_VERSION 4   /* 3: + zedo_reproj_degenerate, zedo_pose_min, zedo_weights_set_math / zedo_weights_get_math;
-                              * 4: + zedo_profile_bracket_ms */
+#define ZEDO_ABI_VERSION 5   /* 3: + zedo_reproj_degenerate, zedo_pose_min, zedo_weights_set_math / zedo_weights_get_math;
+                              * 4: + zedo_profile_bracket_ms;  5: + zedo_probe_mfma_peak_f16, ZEDO_PROF_SEAM (ZEDO_PROF_CLASSES 4 -> 5), workspace rows rounded to 64 again */
 
 #define ZEDO_OK 0
 #define ZEDO_E_BADARG (-1)      /* NULL pointer, non-positive size, unsupported dimension */
@@ -222,14 +222,19 @@ int zedo_pose_min(const double *d_err, int B, int N, long long row_offset, doubl
 #define ZEDO_PROF_HIDDEN 0  /* the four 1024x1024 dense layers (+GroupNorm+SiLU[+residual]) */
 #define ZEDO_PROF_PRE 1     /* pre_dense (+GroupNorm+SiLU) */
 #define ZEDO_PROF_POST 2    /* post_dense + SDE update */
-#define ZEDO_PROF_REPROJ 3  /* reprojection correction */
-#define ZEDO_PROF_CLASSES 4
+#define ZEDO_PROF_REPROJ 3  /* reprojection correction (stand-alone launch: first iteration of a zedo_oil_run call) */
+#define ZEDO_PROF_SEAM 4    /* post_dense + SDE update of iteration i and pre_dense of iteration i + 1 in one launch (zedo_oil_run, large batches) */
+#define ZEDO_PROF_CLASSES 5
 int zedo_profile_start(int sample_every, int max_samples);
 /* What this box's matrix pipe sustains right now: `iters` x 16 back-to-back v_mfma_f32_32x32x2_f32 per wave on every
  * SIMD (two waves each) -> TFLOP/s, and the shader clock seen over that run.  Boxes of one pool differ by a few per
  * cent in clock / power state; bench.py reports the dominant kernel against this number next to the datasheet peak.
  * Synchronises `stream`.  Diagnostic, not part of the data path. */
 int zedo_probe_mfma_peak(int iters, double *h_tflops, double *h_shader_ghz, void *stream);
+/* The same for the fp16 matrix pipe the opt-in split-fp16 mode runs on: `iters` x 16 back-to-back v_mfma_f32_32x32x16_f16 per wave,
+ * two waves per SIMD, operands that differ per lane and per instruction, no LDS / memory traffic.  Under a dense fp16 MFMA stream power
+ * management grants well below the 2.4 GHz the 2.5 PFLOP/s datasheet peak is quoted at: this is the ceiling attainable on this box. */
+int zedo_probe_mfma_peak_f16(int iters, double *h_tflops, double *h_shader_ghz, void *stream);
 int zedo_profile_stop(double *h_total_ms, long long *h_samples, long long *h_launches);
 /* Shader clock (GHz) the sampled hidden-layer launches of the last profiling session really ran at: shader cycles over
  * 100 MHz wall ticks, taken by workgroup 0 of each sampled launch around its tile.  0 if nothing was sampled. */

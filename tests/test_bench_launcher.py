@@ -107,8 +107,8 @@ def test_strong_scaling_projection_reads_the_one_gpu_shard_measurements():
     (profiles/strong_shards_r04.jsonl); the self-check problem is fixed and small."""
     sys.path.insert(0, ROOT)
     import bench
-    r8, ms8 = bench.strong_projection(6344, "f32")           # configs[2] over 8 ranks: 6 344 rows on rank 0, measured at 6 350
-    assert r8 == 6350 and 400 < ms8 < 600
+    r8, ms8, src = bench.strong_projection(6344, "f32")      # configs[2] over 8 ranks: 6 344 rows on rank 0, measured at 6 350
+    assert r8 == 6350 and 400 < ms8 < 600 and src.startswith("profiles/strong_shards_r")
     assert bench.strong_projection(6344, "f16x3")[1] < ms8       # the alt-mode time of the same record
     assert bench.strong_projection(12688, "f32")[0] == 12700 and bench.strong_projection(25375, "f32")[0] == 25400
     assert bench.strong_projection(9000, "f32") is None          # nothing measured within 2 %

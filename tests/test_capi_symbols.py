@@ -37,7 +37,7 @@ def test_header_declares_the_expected_surface():
 def test_library_exports_every_declared_symbol(lib):
     for n in declared_functions():
         assert hasattr(lib, n), f"{n} declared in include/zedo_hip.h but not exported"
-    assert lib.zedo_abi_version() == 4
+    assert lib.zedo_abi_version() == 5
     lib.zedo_error_string.restype = ctypes.c_char_p
     assert b"workspace" in lib.zedo_error_string(-3)
 

@@ -32,7 +32,7 @@ def dev(a, dtype=torch.float32):
 
 
 def test_abi_version(zh):
-    assert zh.abi_version() == 4
+    assert zh.abi_version() == 5
 
 
 def test_schedule_tables(zh, W, weights0, golden):
@@ -328,7 +328,12 @@ import torch
 import zedo_hip as zh
 from lib.dataset import synthetic as syn
 out = {}
-for tag, kl, ipoT, minT, N, H in (("pw3d", list(range(17)), 8.0, 0.2, 301, 3), ("h36m", [0, 1, 4], 3.0, 0.5, 257, 2)):
+# the shipped key lists (17 joints: 3DPW, [0, 1, 4]: H36M) and custom ZeDO.IPO_keylist values of other lengths (round 6: every length
+# 1 .. 17 has its lane-per-row instantiation)
+for tag, kl, ipoT, minT, N, H in (("pw3d", list(range(17)), 8.0, 0.2, 301, 3), ("h36m", [0, 1, 4], 3.0, 0.5, 257, 2),
+                                  ("k1", [0], 3.0, 0.5, 129, 2), ("k5", [0, 2, 5, 11, 14], 3.0, 0.5, 131, 2),
+                                  ("k8", [0, 1, 4, 7, 8, 11, 14, 16], 8.0, 0.2, 130, 2), ("k12", list(range(0, 12)), 8.0, 0.2, 67, 2),
+                                  ("k16", list(range(1, 17)), 8.0, 0.2, 65, 2)):
     d = syn.make_poses(N, seed=5, conf_mode="uniform")
     cl = syn.make_clusters(H, seed=5)
     dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
@@ -348,7 +353,8 @@ def test_ipo_kernels_are_bitwise_twins():
     """The IPO has two kernels - one row per half-wave with a joint per lane (small batches: latency), one lane per row
     (batches that fill the chip: throughput) - chosen by the LOCAL row count.  That is only legitimate if a row's fit does
     not depend on the choice: both are pinned (ZEDO_IPO_KERNEL=half|row, read once per process) on the same problems - the
-    17-joint and the 3-joint key list, z and xyz axes, 500 iterations - and must agree BIT FOR BIT in R, T, q and scale."""
+    17-joint and the 3-joint key list and custom lists of 1, 5, 8, 12 and 16 joints, z and xyz axes, 500 iterations - and must
+    agree BIT FOR BIT in R, T, q and scale."""
     import json
     import os
     import subprocess

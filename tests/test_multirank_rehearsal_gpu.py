@@ -34,7 +34,7 @@ BENCH = os.path.join(ROOT, "bench.py")
 def _env(share):
     e = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ZEDO_FORCE_DIST", "ZEDO_BENCH_FORCE_DIST",
-              "ZEDO_NO_BUILD", "ZEDO_SHARE_DEVICE", "ZEDO_DIST_BACKEND", "ZEDO_BENCH_FAIL_RANK", "ZEDO_BENCH_CORRUPT_RANK"):
+              "ZEDO_NO_BUILD", "ZEDO_SHARE_DEVICE", "ZEDO_DIST_BACKEND", "ZEDO_BENCH_FAIL_RANK", "ZEDO_BENCH_CORRUPT_RANK", "ZEDO_BENCH_CORRUPT_KIND"):
         e.pop(k, None)
     e["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     if share:
@@ -42,10 +42,15 @@ def _env(share):
     return e
 
 
+def a_hypo(args):
+    return int(args[args.index("--hypo") + 1])
+
+
 def _bench(args, share, extra_env=None, ok=True):
     e = _env(share)
     e.update(extra_env or {})
-    r = subprocess.run([sys.executable, BENCH] + args + ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-alt-mode"],
+    r = subprocess.run([sys.executable, BENCH] + args + ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-alt-mode",
+                                                         "--strong-poses", "61", "--strong-steps", "2"],
                        env=e, cwd=ROOT, capture_output=True, text=True, timeout=900)
     if not ok:
         return r
@@ -81,9 +86,23 @@ def test_eight_ranks_on_one_gpu_equal_the_one_rank_run(case):
         assert a["mpjpe_best_of_H_m"] == b["mpjpe_best_of_H_m"] and a["pa_mpjpe_best_of_H_m"] == b["pa_mpjpe_best_of_H_m"]
     assert a["value"] > 0 and a["ms_per_step"] > 0 and a["scaling"] in ("weak", "strong")
     # the run checked itself before it timed anything: 8 ranks == 1 rank on the live transport, every rank's own pass time reported
+    # ... for BOTH exchange kinds, whatever the workload (round 6): the MIN selection and the all-gather
     sc = a["multi_rank_selfcheck"]
-    assert sc["ok"] is True and sc["ranks"] == 8 and sc["backend"] == "gloo" and sc["sha"] == sc["sha_unsharded"] and len(sc["sha"]) == 16
-    assert b["multi_rank_selfcheck"] is None
+    assert sc["ok"] is True and sc["ranks"] == 8 and sc["backend"] == "gloo"
+    for kind in ("selection", "gather"):
+        assert sc[kind]["ok"] is True and sc[kind]["sha"] == sc[kind]["sha_unsharded"] and len(sc[kind]["sha"]) == 16
+    assert sc["selection"]["sha"] != sc["gather"]["sha"]
+    assert b["multi_rank_selfcheck"] is None and b["strong"] is None
+    # ... and, beside a workload-2 headline, the `strong` object: one fixed problem on rank 0 alone against the same problem split over
+    # the 8 ranks + the exchange, timed back to back, the two selections bit-identical
+    st = a["strong"]
+    if a["config"]["baseline_config"] == 2:
+        assert st["scaling"] == "strong" and st["n_gpus"] == 8 and st["steps"] == 2 and st["rows_per_gpu"] == -(-61 * a_hypo(multi) // 8)
+        assert st["matches_one_rank"] is True and st["selection_sha16"] == st["one_rank_selection_sha16"] and len(st["selection_sha16"]) == 16
+        assert st["ms_per_step"] > 0 and st["one_rank"]["ms_per_step"] > 0 and st["speedup_vs_one_rank"] > 0 and st["efficiency"] > 0
+        assert len(st["rank_pass_s"]["all"]) == 8 and st["efficiency_vs_projection"] is None        # non-stated size: nothing to project from
+    else:
+        assert st is None
     rp = a["rank_pass_s"]
     assert len(rp["all"]) == 8 and rp["min"] <= rp["max"] and rp["all"][rp["argmax"]] == rp["max"] and abs(rp["max"] * 1e3 - a["ms_per_step"]) < 0.02
 
@@ -96,14 +115,19 @@ def test_a_failing_rank_other_than_zero_fails_the_launcher():
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
-@pytest.mark.parametrize("workload", ["2", "4"])
-def test_a_corrupted_shard_fails_the_selfcheck_before_anything_is_timed(workload):
+@pytest.mark.parametrize("workload,kind", [("2", None), ("4", None), ("2", "gather"), ("4", "selection")])
+def test_a_corrupted_shard_fails_the_selfcheck_before_anything_is_timed(workload, kind):
     """ZEDO_BENCH_CORRUPT_RANK=3: rank 3 of 8 moves its shard by a millimetre before the exchange step of the self-check; the
     sharded digest then differs from rank 0's unsharded one, every rank exits with code 4 and no JSON line is printed - a
-    wrong N-rank result cannot yield a number (selection exchange and the all-gather of run.inference alike)."""
-    r = _bench(["--gpus", "8", "--workload", workload, "--poses", "8", "--hypo", "3", "--oil", "10"], share=True,
-               extra_env={"ZEDO_BENCH_CORRUPT_RANK": "3"}, ok=False)
+    wrong N-rank result cannot yield a number.  Both exchange kinds are checked in every run (round 6): corrupting ONLY the
+    all-gather's input fails a selection workload, corrupting ONLY the selection's input fails the gather workload."""
+    env = {"ZEDO_BENCH_CORRUPT_RANK": "3"}
+    if kind:
+        env["ZEDO_BENCH_CORRUPT_KIND"] = kind
+    r = _bench(["--gpus", "8", "--workload", workload, "--poses", "8", "--hypo", "3", "--oil", "10"], share=True, extra_env=env, ok=False)
     assert r.returncode == 4 and "multi_rank_selfcheck FAILED" in r.stderr, (r.returncode, r.stderr[-2000:])
+    for k in ("selection", "gather"):
+        assert (f"FAILED ({k})" in r.stderr) == (kind in (None, k)), (k, kind, r.stderr[-2000:])
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 

@@ -43,7 +43,7 @@ def _run(cmd, dist, cwd=ROOT):
 
 def test_bench_exchange_step_on_rccl_is_bit_identical():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--oil", "20", "--poses", "64",
-           "--hypo", "5", "--no-cpu-baseline"]
+           "--hypo", "5", "--no-cpu-baseline", "--strong-poses", "96", "--strong-steps", "2"]
     lines = {}
     for dist in (False, True):
         out = _run(cmd, dist)
@@ -71,6 +71,16 @@ def test_bench_exchange_step_on_rccl_is_bit_identical():
         assert rf["avg_launch_ms"] <= rf["avg_launch_ms_bracketed"]
     assert a["selection_sha16"] == b["selection_sha16"], (a["selection_sha16"], b["selection_sha16"])
     assert a["mpjpe_best_of_H_m"] == b["mpjpe_best_of_H_m"] and a["pa_mpjpe_best_of_H_m"] == b["pa_mpjpe_best_of_H_m"]
+    # a run with a process group (here: RCCL, one member) carries the self-check of BOTH exchange kinds and the `strong` object
+    assert a["multi_rank_selfcheck"] is None and a["strong"] is None
+    sc = b["multi_rank_selfcheck"]
+    assert sc["ok"] and sc["backend"] == "nccl" and sc["ranks"] == 1
+    for kind in ("selection", "gather"):
+        assert sc[kind]["ok"] and sc[kind]["sha"] == sc[kind]["sha_unsharded"] and len(sc[kind]["sha"]) == 16
+    st = b["strong"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 1 and st["matches_one_rank"] and st["selection_sha16"] == st["one_rank_selection_sha16"]
+    assert st["ms_per_step"] > 0 and st["one_rank"]["ms_per_step"] > 0 and 0.5 < st["speedup_vs_one_rank"] < 1.5
+    assert st["alt_mode"]["math"] == "f16x3" and st["alt_mode"]["matches_one_rank"]
 
 
 DRIVER = r'''

@@ -74,7 +74,7 @@ struct Prof {
     double bracket_ms = 0.0;      // result of the last session: what an EMPTY event pair on the launch stream measures
     hipStream_t last_stream = nullptr;
     size_t used = 0;
-    long long seen[ZEDO_PROF_CLASSES] = {0, 0, 0, 0};
+    long long seen[ZEDO_PROF_CLASSES] = {};
 } g_prof;
 
 struct ProfScope {
@@ -100,6 +100,13 @@ extern "C" int zedo_probe_mfma_peak(int iters, double *h_tflops, double *h_shade
     if (iters < 1000 || iters > 10000000) return ZEDO_E_BADARG;
     if (int rc = check_device_fwd()) return rc;
     HIPCHK(probe_mfma_peak(iters, h_tflops, h_shader_ghz, (hipStream_t)stream));
+    return ZEDO_OK;
+}
+
+extern "C" int zedo_probe_mfma_peak_f16(int iters, double *h_tflops, double *h_shader_ghz, void *stream) {
+    if (iters < 1000 || iters > 10000000) return ZEDO_E_BADARG;
+    if (int rc = check_device_fwd()) return rc;
+    HIPCHK(probe_mfma_peak(iters, h_tflops, h_shader_ghz, (hipStream_t)stream, true));
     return ZEDO_OK;
 }
 
@@ -133,8 +140,8 @@ extern "C" double zedo_profile_bracket_ms(void) { return g_prof.bracket_ms; }
 extern "C" int zedo_profile_stop(double *h_total_ms, long long *h_samples, long long *h_launches) {
     g_prof.on.store(false, std::memory_order_release);
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    double tot[ZEDO_PROF_CLASSES] = {0, 0, 0, 0};
-    long long cnt[ZEDO_PROF_CLASSES] = {0, 0, 0, 0};
+    double tot[ZEDO_PROF_CLASSES] = {};
+    long long cnt[ZEDO_PROF_CLASSES] = {};
     for (size_t i = 0; i < g_prof.used; ++i) {
         HIPCHK(hipEventSynchronize(g_prof.pool[i].b));
         float ms = 0.f;
@@ -495,84 +502,115 @@ struct NextReproj {          // reprojection of the next loop iteration, fused i
     long long row0 = 0;
 };
 
-// ZEDO_MATH_F16X3: the same six layers on the fp16 matrix pipe (zedo_gemm16.hip).  h / h1 hold the activations as split-fp16
-// planes (the same 4 bytes per element); the pose state xpad, the time-bias rows and the SDE / reprojection epilogue stay fp32.
-static hipError_t mlp_layers_f16(const zedo_weights *w, const float *tb, float *xpad, float *h, float *h1, int Bp, int ld, bool sde,
-                                 float sa, float sc, float *eps_out, hipStream_t st, const NextReproj &nr) {
-    const size_t per = (size_t)HID * HID * 2;                 // uint16 per hidden weight matrix
-    const uint16_t *W_pre16 = w->d_W16 + 4 * per, *W_post16 = W_pre16 + (size_t)HID * XLD * 2;
-    hipError_t e;
-    {   // pre_dense + pre_gnorm + SiLU: X = the fp32 pose rows, split by the kernel
-        Layer16Args b{};
-        b.K = XLD; b.N = HID; b.Mp = Bp; b.ldo = ld; b.Xf32 = xpad; b.W = W_pre16; b.unscale = w->unscale[4];
-        b.bias = tb; b.gamma = w->gamma[0]; b.beta = w->beta[0]; b.out = h; b.out_f32 = 0;
-        ProfScope ps(ZEDO_PROF_PRE, st);
-        e = launch_layer16(b, EPI_GN_SILU, st);
-    }
-    for (int blk = 0; blk < 2 && e == hipSuccess; ++blk) {
-        const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
-        Layer16Args b{};
-        b.K = HID; b.N = HID; b.Mp = Bp; b.ldx = b.ldo = ld; b.out_f32 = 0;
-        b.X = reinterpret_cast<const uint16_t *>(h); b.W = w->d_W16 + (size_t)(l1 - 1) * per; b.unscale = w->unscale[l1 - 1];
-        b.bias = tb + (size_t)l1 * HID; b.gamma = w->gamma[l1]; b.beta = w->beta[l1]; b.out = h1;
-        { ProfScope ps(ZEDO_PROF_HIDDEN, st); b.clk = ps.clk; e = launch_layer16(b, EPI_GN_SILU, st); b.clk = nullptr; }
-        if (e != hipSuccess) break;
-        // h = h + h2: the residual comes from h's planes and the sum goes back into them, in place
-        b.X = reinterpret_cast<const uint16_t *>(h1); b.W = w->d_W16 + (size_t)(l2 - 1) * per; b.unscale = w->unscale[l2 - 1];
-        b.bias = tb + (size_t)l2 * HID; b.gamma = w->gamma[l2]; b.beta = w->beta[l2];
-        b.res = reinterpret_cast<const uint16_t *>(h); b.out = h;
-        { ProfScope ps(ZEDO_PROF_HIDDEN, st); b.clk = ps.clk; e = launch_layer16(b, EPI_GN_SILU_RES, st); b.clk = nullptr; }
-    }
-    if (e != hipSuccess) return e;
-    Layer16Args b{};
-    b.K = HID; b.N = XLD; b.Mp = Bp; b.ldx = ld; b.X = reinterpret_cast<const uint16_t *>(h);
-    b.W = W_post16; b.unscale = w->unscale[5]; b.bias = w->b_post;
-    ProfScope ps(ZEDO_PROF_POST, st);
-    if (sde) {
-        b.xio = xpad; b.sde_a = sa; b.sde_c = sc;
-        b.rp_geom = nr.geom; b.rp_T = nr.T; b.rp_solve = nr.solve; b.rp_B = nr.B; b.rp_N = nr.N; b.rp_row0 = nr.row0;
-        return launch_layer16(b, EPI_SDE, st);
-    }
-    b.out = eps_out;
-    return launch_layer16(b, EPI_BIAS, st);
-}
+// The six dense layers of one score-network evaluation (model.py:264-291) as three pieces - pre_dense, the four hidden layers,
+// post_dense - so that zedo_oil_run can put post_dense of iteration i and pre_dense of iteration i + 1 into ONE launch (the seam
+// kernels of zedo_gemm.hip / zedo_gemm16.hip).  h / h1: activations [rows][1024] fp32 (exact-fp32 mode) or split-fp16 planes
+// (ZEDO_MATH_F16X3: the same 4 bytes per element, k-block-major with `ld` rows per k block); the pose state xpad, the time-bias rows
+// and the SDE / reprojection epilogue are fp32 in both modes.
+struct Net {
+    const zedo_weights *w;
+    float *xpad, *h, *h1;
+    int Bp, ld;
+    hipStream_t st;
+    bool f16() const { return w->math == ZEDO_MATH_F16X3; }
+    const uint16_t *W_pre16() const { return w->d_W16 + 4 * (size_t)HID * HID * 2; }
+    const uint16_t *W_post16() const { return W_pre16() + (size_t)HID * XLD * 2; }
 
-// ld: rows of the workspace buffers h / h1 (>= Bp): the split-fp16 mode stores its activations k-block-major, [channel / 16][ld][64 bytes]
-static hipError_t mlp_layers(const zedo_weights *w, const float *tb, float *xpad, float *h, float *h1, int Bp, int ld, bool sde,
-                             float sa, float sc, float *eps_out, hipStream_t st, const NextReproj &nr = NextReproj()) {
-    if (w->math == ZEDO_MATH_F16X3) return mlp_layers_f16(w, tb, xpad, h, h1, Bp, ld, sde, sa, sc, eps_out, st, nr);
-    LayerArgs a{};
-    a.Mp = Bp;
+    LayerArgs pre_args(const float *tb) const {
+        LayerArgs a{};
+        a.Mp = Bp; a.X = xpad; a.ldx = XLD; a.W = w->W_pre; a.ldw = XLD; a.K = XLD; a.N = HID;
+        a.kzero8 = w->J3 <= XLD - 8;   // 51 real inputs: k = 56..63 are zero in xpad and in the padded weight
+        a.bias = tb; a.gamma = w->gamma[0]; a.beta = w->beta[0]; a.out = h; a.ldo = HID;
+        return a;
+    }
+    Layer16Args pre_args16(const float *tb) const {     // X = the fp32 pose rows, split by the kernel
+        Layer16Args b{};
+        b.K = XLD; b.N = HID; b.Mp = Bp; b.ldo = ld; b.Xf32 = xpad; b.W = W_pre16(); b.unscale = w->unscale[4];
+        b.bias = tb; b.gamma = w->gamma[0]; b.beta = w->beta[0]; b.out = h; b.out_f32 = 0;
+        return b;
+    }
+    LayerArgs post_args(bool sde, float sa, float sc, float *eps_out, const NextReproj &nr) const {
+        LayerArgs a{};
+        a.Mp = Bp; a.X = h; a.ldx = HID; a.W = w->W_post; a.ldw = HID; a.K = HID; a.N = XLD; a.bias = w->b_post; a.ldo = XLD;
+        a.scratch = h1 + (size_t)Bp * XLD;      // h1 is free here ([Bp][XLD] of it may hold eps_out): K-quarter sums of small batches
+        if (sde) {
+            a.out = xpad; a.sde_a = sa; a.sde_c = sc;
+            a.rp_geom = nr.geom; a.rp_T = nr.T; a.rp_solve = nr.solve; a.rp_B = nr.B; a.rp_N = nr.N; a.rp_row0 = nr.row0;
+        } else {
+            a.out = eps_out;
+        }
+        return a;
+    }
+    Layer16Args post_args16(bool sde, float sa, float sc, float *eps_out, const NextReproj &nr) const {
+        Layer16Args b{};
+        b.K = HID; b.N = XLD; b.Mp = Bp; b.ldx = ld; b.X = reinterpret_cast<const uint16_t *>(h);
+        b.W = W_post16(); b.unscale = w->unscale[5]; b.bias = w->b_post;
+        if (sde) {
+            b.xio = xpad; b.sde_a = sa; b.sde_c = sc;
+            b.rp_geom = nr.geom; b.rp_T = nr.T; b.rp_solve = nr.solve; b.rp_B = nr.B; b.rp_N = nr.N; b.rp_row0 = nr.row0;
+        } else {
+            b.out = eps_out;
+        }
+        return b;
+    }
+
     // pre_dense + pre_gnorm + SiLU
-    a.X = xpad; a.ldx = XLD; a.W = w->W_pre; a.ldw = XLD; a.K = XLD; a.N = HID;
-    a.kzero8 = w->J3 <= XLD - 8;   // 51 real inputs: k = 56..63 are zero in xpad and in the padded weight
-    a.bias = tb; a.gamma = w->gamma[0]; a.beta = w->beta[0]; a.out = h; a.ldo = HID;
-    hipError_t e;
-    { ProfScope ps(ZEDO_PROF_PRE, st); e = launch_layer(a, EPI_GN_SILU, st); }
-    a.kzero8 = 0;
-    for (int blk = 0; blk < 2 && e == hipSuccess; ++blk) {
-        const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
-        a.X = h; a.ldx = HID; a.W = w->W_hid[l1 - 1]; a.ldw = HID; a.K = HID; a.N = HID;
-        a.bias = tb + (size_t)l1 * HID; a.gamma = w->gamma[l1]; a.beta = w->beta[l1]; a.out = h1; a.ldo = HID;
-        { ProfScope ps(ZEDO_PROF_HIDDEN, st); a.clk = ps.clk; e = launch_layer(a, EPI_GN_SILU, st); a.clk = nullptr; }
-        if (e != hipSuccess) break;
-        a.X = h1; a.W = w->W_hid[l2 - 1];
-        a.bias = tb + (size_t)l2 * HID; a.gamma = w->gamma[l2]; a.beta = w->beta[l2]; a.out = h;  // h = h + h2, in place
-        { ProfScope ps(ZEDO_PROF_HIDDEN, st); a.clk = ps.clk; e = launch_layer(a, EPI_GN_SILU_RES, st); a.clk = nullptr; }
+    hipError_t pre(const float *tb) const {
+        ProfScope ps(ZEDO_PROF_PRE, st);
+        if (f16()) return launch_layer16(pre_args16(tb), EPI_GN_SILU, st);
+        return launch_layer(pre_args(tb), EPI_GN_SILU, st);
     }
-    if (e != hipSuccess) return e;
-    a.X = h; a.ldx = HID; a.W = w->W_post; a.ldw = HID; a.K = HID; a.N = XLD; a.bias = w->b_post;
-    a.gamma = a.beta = nullptr; a.ldo = XLD;
-    a.scratch = h1 + (size_t)Bp * XLD;      // h1 is free here ([Bp][XLD] of it may hold eps_out): K-quarter sums of small batches
-    ProfScope ps(ZEDO_PROF_POST, st);
-    if (sde) {
-        a.out = xpad; a.sde_a = sa; a.sde_c = sc;
-        a.rp_geom = nr.geom; a.rp_T = nr.T; a.rp_solve = nr.solve; a.rp_B = nr.B; a.rp_N = nr.N; a.rp_row0 = nr.row0;
-        return launch_layer(a, EPI_SDE, st);
+    // the two residual blocks: h1 = f(h); h = h + f(h1), twice
+    hipError_t hidden(const float *tb) const {
+        hipError_t e = hipSuccess;
+        for (int blk = 0; blk < 2 && e == hipSuccess; ++blk) {
+            const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
+            if (f16()) {
+                const size_t per = (size_t)HID * HID * 2;                 // uint16 per hidden weight matrix
+                Layer16Args b{};
+                b.K = HID; b.N = HID; b.Mp = Bp; b.ldx = b.ldo = ld; b.out_f32 = 0;
+                b.X = reinterpret_cast<const uint16_t *>(h); b.W = w->d_W16 + (size_t)(l1 - 1) * per; b.unscale = w->unscale[l1 - 1];
+                b.bias = tb + (size_t)l1 * HID; b.gamma = w->gamma[l1]; b.beta = w->beta[l1]; b.out = h1;
+                { ProfScope ps(ZEDO_PROF_HIDDEN, st); b.clk = ps.clk; e = launch_layer16(b, EPI_GN_SILU, st); b.clk = nullptr; }
+                if (e != hipSuccess) break;
+                // h = h + h2: the residual comes from h's planes and the sum goes back into them, in place
+                b.X = reinterpret_cast<const uint16_t *>(h1); b.W = w->d_W16 + (size_t)(l2 - 1) * per; b.unscale = w->unscale[l2 - 1];
+                b.bias = tb + (size_t)l2 * HID; b.gamma = w->gamma[l2]; b.beta = w->beta[l2];
+                b.res = reinterpret_cast<const uint16_t *>(h); b.out = h;
+                { ProfScope ps(ZEDO_PROF_HIDDEN, st); b.clk = ps.clk; e = launch_layer16(b, EPI_GN_SILU_RES, st); b.clk = nullptr; }
+            } else {
+                LayerArgs a{};
+                a.Mp = Bp; a.X = h; a.ldx = HID; a.W = w->W_hid[l1 - 1]; a.ldw = HID; a.K = HID; a.N = HID;
+                a.bias = tb + (size_t)l1 * HID; a.gamma = w->gamma[l1]; a.beta = w->beta[l1]; a.out = h1; a.ldo = HID;
+                { ProfScope ps(ZEDO_PROF_HIDDEN, st); a.clk = ps.clk; e = launch_layer(a, EPI_GN_SILU, st); a.clk = nullptr; }
+                if (e != hipSuccess) break;
+                a.X = h1; a.W = w->W_hid[l2 - 1];
+                a.bias = tb + (size_t)l2 * HID; a.gamma = w->gamma[l2]; a.beta = w->beta[l2]; a.out = h;  // h = h + h2, in place
+                { ProfScope ps(ZEDO_PROF_HIDDEN, st); a.clk = ps.clk; e = launch_layer(a, EPI_GN_SILU_RES, st); a.clk = nullptr; }
+            }
+        }
+        return e;
     }
-    a.out = eps_out;
-    return launch_layer(a, EPI_BIAS, st);
-}
+    // post_dense, ending either in eps -> eps_out (EPI_BIAS, zedo_score_eps) or in the SDE update of xpad (EPI_SDE) [+ nr]
+    hipError_t post(bool sde, float sa, float sc, float *eps_out, const NextReproj &nr) const {
+        ProfScope ps(ZEDO_PROF_POST, st);
+        if (f16()) return launch_layer16(post_args16(sde, sa, sc, eps_out, nr), sde ? EPI_SDE : EPI_BIAS, st);
+        return launch_layer(post_args(sde, sa, sc, eps_out, nr), sde ? EPI_SDE : EPI_BIAS, st);
+    }
+    // post_dense + SDE update [+ nr] of one iteration and pre_dense of the next (time-bias rows tb_next) in one launch;
+    // hipErrorNotSupported: this batch shape has no seam kernel (the caller issues the two launches)
+    hipError_t seam(float sa, float sc, const NextReproj &nr, const float *tb_next) const {
+        ProfScope ps(ZEDO_PROF_SEAM, st);
+        if (f16()) return launch_seam16(post_args16(true, sa, sc, nullptr, nr), pre_args16(tb_next), st);
+        return launch_seam(post_args(true, sa, sc, nullptr, nr), pre_args(tb_next), st);
+    }
+    hipError_t all(const float *tb, bool sde, float sa, float sc, float *eps_out, const NextReproj &nr = NextReproj()) const {
+        hipError_t e = pre(tb);
+        if (e == hipSuccess) e = hidden(tb);
+        if (e == hipSuccess) e = post(sde, sa, sc, eps_out, nr);
+        return e;
+    }
+};
 
 struct Ws { float *xpad, *h, *h1; size_t rows; };
 static Ws carve(void *ws, int B) {
@@ -591,12 +629,13 @@ static int step_common(const zedo_weights_t *w, const zedo_schedule_t *s, int st
         const int Bc = (int)std::min(cap, (size_t)B - r0), Bp = round_up(Bc, BATCH_PAD);
         Ws k = carve(ws, B);
         HIPCHK(launch_pack_rows(d_x_in + r0 * w->J3, k.xpad, Bc, Bp, w->J3, st));
+        const Net net{w, k.xpad, k.h, k.h1, Bp, (int)k.rows, st};
         if (sde) {
-            HIPCHK(mlp_layers(w, tb, k.xpad, k.h, k.h1, Bp, (int)k.rows, true, s->a[step], s->c[step], nullptr, st));
+            HIPCHK(net.all(tb, true, s->a[step], s->c[step], nullptr));
             HIPCHK(launch_unpack_rows(k.xpad, d_out + r0 * w->J3, Bc, w->J3, st));
         } else {
             // eps lands in h1's first XLD columns region: reuse h1 as [Bp][XLD]
-            HIPCHK(mlp_layers(w, tb, k.xpad, k.h, k.h1, Bp, (int)k.rows, false, 0.f, 0.f, k.h1, st));
+            HIPCHK(net.all(tb, false, 0.f, 0.f, k.h1));
             HIPCHK(launch_unpack_rows(k.h1, d_out + r0 * w->J3, Bc, w->J3, st));
         }
     }
@@ -632,7 +671,13 @@ extern "C" int zedo_oil_run(const zedo_weights_t *w, const zedo_schedule_t *s, f
         // correction of every later iteration i+1 rides in the epilogue of iteration i's post_dense launch
         // (ZEDO_UNFUSED_REPROJ=1: one launch per iteration, the A/B and parity reference)
         static const bool unfused = getenv("ZEDO_UNFUSED_REPROJ") != nullptr;
+        // post_dense of iteration i and pre_dense of iteration i + 1 share a launch wherever the batch shape has a seam kernel
+        // (round 6; ZEDO_NO_SEAM=1: two launches, the A/B and bitwise reference of the seam)
+        static const bool no_seam = getenv("ZEDO_NO_SEAM") != nullptr;
+        const Net net{w, k.xpad, k.h, k.h1, Bp, (int)k.rows, st};
+        bool pre_done = false;             // pre_dense of iteration i was issued by iteration i - 1's seam launch
         for (int i = step_begin; i < step_end; ++i) {
+            const float *tb = s->d_tbias + (size_t)i * NLAYER * HID;
             if (i == step_begin || unfused) {
                 ProfScope ps(ZEDO_PROF_REPROJ, st);
                 HIPCHK(launch_reproj_step_padded(k.xpad, d_geom, d_T + r0 * 3, i >= switch_step, Bc, N,
@@ -644,8 +689,15 @@ extern "C" int zedo_oil_run(const zedo_weights_t *w, const zedo_schedule_t *s, f
                 nr.row0 = row_offset + (long long)r0;
             }
             // sampling_fn(...) (run/opt_main.py:210-218) -> x = a_i x + c_i eps(x, t_i)  [+ the next correction]
-            HIPCHK(mlp_layers(w, s->d_tbias + (size_t)i * NLAYER * HID, k.xpad, k.h, k.h1, Bp, (int)k.rows, true, s->a[i], s->c[i],
-                              nullptr, st, nr));
+            if (!pre_done) HIPCHK(net.pre(tb));
+            HIPCHK(net.hidden(tb));
+            pre_done = false;
+            if (i + 1 < step_end && !unfused && !no_seam) {
+                const hipError_t e = net.seam(s->a[i], s->c[i], nr, tb + (size_t)NLAYER * HID);
+                if (e == hipSuccess) { pre_done = true; continue; }
+                if (e != hipErrorNotSupported) return (int)e;
+            }
+            HIPCHK(net.post(true, s->a[i], s->c[i], nullptr, nr));
         }
         HIPCHK(launch_unpack_rows(k.xpad, d_x + r0 * w->J3, Bc, w->J3, st));
     }

@@ -606,6 +606,45 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
     return hipErrorInvalidValue;
 }
 
+// ---- the seam of two loop iterations in ONE launch (round 6) -----------------------------------------------------------
+// post_dense of iteration i (+ SDE update + reprojection correction of iteration i + 1) and pre_dense (+ GroupNorm + SiLU) of
+// iteration i + 1 touch the same 64 pose rows: a workgroup runs post_dense's 64x64 tile (K summed as four quarter chains, as in
+// every other shape), leaves the updated rows in the pose state, and goes straight on to the eight 64x128 column tiles of
+// pre_dense on those rows - the SAME layer_tile code as the two separate launches (same products, same order: bit-identical),
+// one launch instead of two, and the 208 MB read of post_dense's activations overlaps the 208 MB pre_dense writes (different
+// workgroups are in different phases).  The pose rows reach phase B's LDS-DMA through this CU's vector L1 / the L2: they were
+// stored by this very workgroup, every wave waits for its stores (vmcnt) before the barrier, and a workgroup's waves share one L1.
+// pre_dense writes the activation rows post_dense has just read (in place, as the two launches do): a workgroup's phase A has
+// consumed its 64 rows completely before its phase B writes them, and no other workgroup touches them.
+__global__ __launch_bounds__(256, 2) void seam_kernel(LayerArgs post, LayerArgs pre) {
+    const int m0 = (int)blockIdx.x * 64;
+    layer_tile<64, 64, 2, 2, EPI_SDE, 4, 32, SCHED_THIN, 0, 4>(post, m0, 0, m0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores of the updated pose rows have completed
+    __syncthreads();                                       // ... every wave's: the rows are phase B's X operand; the stage is free
+    const int ncol = pre.N / 128;
+    for (int c = 0; c < ncol; ++c) {
+        layer_tile<64, 128, 2, 2, EPI_GN_SILU, 2, 32, SCHED_THIN, 1, 1>(pre, m0, c * 128, m0);
+        __syncthreads();                                   // the tile's stage and parameter block become the next tile's ring
+    }
+}
+
+// -> hipErrorNotSupported when the batch takes another post_dense shape (small batches: quarter tiles + post_reduce_kernel, 32-row
+// tiles): the caller then issues the two launches.
+hipError_t launch_seam(const LayerArgs &post, const LayerArgs &pre, hipStream_t st) {
+    // from one 64-row tile per CU up: below that the eight column tiles of pre_dense are better spread over eight workgroups
+    if (post.Mp <= 8192 || post.Mp < num_cus() * SEAM_MIN_TILES_PER_CU * 64 || post.Mp % 64 || post.Mp != pre.Mp) return hipErrorNotSupported;
+    if (post.N != XLD || post.K % (4 * 32 * 4) || pre.K != 2 * 32 || !pre.kzero8 || pre.N % 128) return hipErrorNotSupported;
+    constexpr size_t ring_post = (size_t)4 * (64 + 64) * 32, stage_post = (size_t)2 * 32 * 64, par_post = 3 * 64;
+    constexpr size_t ring_pre = (size_t)2 * (64 + 128) * 32, stage_pre = (size_t)2 * 32 * 128, par_pre = 3 * 128;
+    constexpr size_t lds_post = (ring_post > stage_post ? ring_post : stage_post) + par_post;
+    constexpr size_t lds_pre = (ring_pre > stage_pre ? ring_pre : stage_pre) + par_pre;
+    constexpr size_t lds = (lds_post > lds_pre ? lds_post : lds_pre) * sizeof(float);
+    static std::atomic<bool> attr_done[MAX_DEVICES];
+    if (hipError_t e = allow_lds(reinterpret_cast<const void *>(seam_kernel), lds, attr_done); e != hipSuccess) return e;
+    hipLaunchKernelGGL(seam_kernel, dim3(post.Mp / 64), dim3(256), lds, st, post, pre);
+    return hipGetLastError();
+}
+
 // ---- diagnostic: what this box's matrix pipe sustains right now (clock / power state differ box to box) ----------
 __global__ __launch_bounds__(256) void mfma_probe_kernel(float *out, int iters, long long *clk) {
     f32x16 acc[4];
@@ -625,7 +664,40 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(float *out, int iters, 
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStream_t st) {
+// The fp16 twin: a bare v_mfma_f32_32x32x16_f16 stream (what the split-fp16 hidden layers issue, zedo_gemm16.hip), two waves per SIMD,
+// four independent accumulators per wave, operands that differ per lane and per instruction (two alternating fragment sets of
+// pseudo-random fp16 values: the power a matrix pipe draws, and with it the clock power management grants, depends on the bits that
+// toggle) - no LDS, no vector memory.  -> what THIS box's fp16 matrix pipe sustains at the clock it is granted under a pure MFMA load:
+// the attainable ceiling that the 2.5 PFLOP/s datasheet figure (quoted at 2.4 GHz) is not.
+__global__ __launch_bounds__(256) void mfma16_probe_kernel(float *out, int iters, long long *clk) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    f16x8 fa[4], fb[4];
+    unsigned h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u + 17u);
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 8; ++e) {
+            h = h * 1664525u + 1013904223u; fa[i][e] = (_Float16)(((int)(h >> 20) - 2048) * (1.0f / 4096.0f));
+            h = h * 1664525u + 1013904223u; fb[i][e] = (_Float16)(((int)(h >> 20) - 2048) * (1.0f / 4096.0f));
+        }
+    long long t0 = 0, w0 = 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { t0 = clock64(); w0 = wall_clock64(); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s0 = (u & 1) * 2;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s0], fb[s0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s0], fb[s0 + 1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s0 + 1], fb[s0], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s0 + 1], fb[s0 + 1], acc[3], 0, 0, 0);
+        }
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = clock64() - t0; clk[1] = wall_clock64() - w0; }
+    float s = 0;
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStream_t st, bool f16) {
     const int blocks = num_cus() * 2;          // 2 blocks of 4 waves per CU: 2 waves per SIMD, dependent chains hidden
     float *d_out = nullptr;
     long long *d_clk = nullptr, clk[2] = {0, 0};
@@ -636,12 +708,14 @@ hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStr
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, d_out, iters / 4, d_clk);   // warm the clocks
+        if (f16) hipLaunchKernelGGL(mfma16_probe_kernel, dim3(blocks), dim3(256), 0, st, d_out, iters / 4, d_clk);   // warm the clocks
+        else hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, d_out, iters / 4, d_clk);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(e0, st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, d_out, iters, d_clk);
+        if (f16) hipLaunchKernelGGL(mfma16_probe_kernel, dim3(blocks), dim3(256), 0, st, d_out, iters, d_clk);
+        else hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, d_out, iters, d_clk);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(e1, st);
@@ -649,7 +723,7 @@ hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStr
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
     if (e == hipSuccess) e = hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost);
     if (e == hipSuccess) {
-        const double flop = (double)blocks * 4 * iters * 16 * 2.0 * 32 * 32 * 2;
+        const double flop = (double)blocks * 4 * iters * 16 * 2.0 * 32 * 32 * (f16 ? 16 : 2);     // 4 waves x iters x 16 MFMAs of 32x32xK
         if (tflops) *tflops = flop / ms / 1e9;
         if (shader_ghz) *shader_ghz = clk[1] > 0 ? (double)clk[0] / ((double)clk[1] / 100e6) / 1e9 : 0.0;   // wall_clock64 ticks at 100 MHz
     } else {

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(64) void ipo_kernel(const float *__restrict__ x0, c
 // terms in the pairing tree half_sum spells with cross-lane moves - slots 0..31, slot j = key joint j, exact +0 beyond K:
 //   a[i] = t[i] + t[15 - i], b[i] = a[i] + a[7 - i], c[i] = b[i] + b[i ^ 2], d = c[0] + c[1] per 16-slot row; sum = d(row 0) + d(row 1)
 // (what lanes 0 and 16 of a half-wave compute; every other lane computes the same bits, addition being commutative).
-// K is a template parameter (the shipped key lists: 3 and 17 joints) so that the tree unrolls over registers.
+// K is a template parameter (one instantiation per key-list length 1 .. 17) so that the tree unrolls over registers.
 constexpr int IPO_ROW_TB = 128;
 template <int KJ, int S>
 __device__ __forceinline__ void ipo_slot(const float (&K)[9], const float (&T0)[3], const IpoRot &o, const float (&x)[KJ], const float (&y)[KJ],
@@ -695,20 +695,28 @@ hipError_t launch_ipo_fit(const float *x0, const float *uv, const float *K, cons
     // 1 000 rows whatever the key list; the row kernel takes 2.57 ms with 17 joints and 0.72 ms with 3 up to 65 536 rows).  Both produce the same bits (one pairing tree), so
     // the choice may depend on the LOCAL row count without breaking shard invariance.  ZEDO_IPO_KERNEL=half|row pins it.
     static const char *pin = getenv("ZEDO_IPO_KERNEL");
-    const bool has_row = (k == 3 || k == 17);
-    // crossover in rows per CU of the CURRENT device (measured on 256 CUs: 17 408 rows with 17 key joints, 4 096 with 3)
-    bool row = has_row && B >= num_cus() * (k == 17 ? 68 : 16);
+    // crossover in rows per CU of the CURRENT device.  Measured on 256 CUs: 17 408 rows (68 per CU) with 17 key joints, 4 096 (16 per CU)
+    // with 3; in between the row kernel's time is linear in the number of key joints (0.32 + 0.13 k ms against the half-wave kernel's
+    // 0.49 ms + 0.13 ms per 1 000 rows beyond 2 000): ~4 k + 4 rows per CU.  Round 6: EVERY key-list length 1 .. 17 has its lane-per-row
+    // instantiation (until round 5 only the shipped 3 and 17: a custom ZeDO.IPO_keylist at configs[3]'s 3.5 M-row shard stayed on the
+    // half-wave kernel, +0.46 s per pass).
+    bool row = B >= num_cus() * (k == 17 ? 68 : 4 * k + 4);
     if (pin && pin[0] == 'h') row = false;
-    if (pin && pin[0] == 'r' && has_row) row = true;
+    if (pin && pin[0] == 'r') row = true;
     const float inv_norm = (float)(1.0 / normaliser);
     if (row) {
         const dim3 grid((B + IPO_ROW_TB - 1) / IPO_ROW_TB), block(IPO_ROW_TB);
-        if (k == 17)
-            hipLaunchKernelGGL(ipo_row_kernel<17>, grid, block, 0, st, x0, uv, K, keys, axes_mask, ipo_T, min_scale, max_scale, iters, inv_norm, R, T,
-                               q, scale, state, it_begin, b1p0, b2p0, B, N, J, row_offset);
-        else
-            hipLaunchKernelGGL(ipo_row_kernel<3>, grid, block, 0, st, x0, uv, K, keys, axes_mask, ipo_T, min_scale, max_scale, iters, inv_norm, R, T,
-                               q, scale, state, it_begin, b1p0, b2p0, B, N, J, row_offset);
+#define ZEDO_IPO_ROW_CASE(KJ)                                                                                                                   \
+        case KJ:                                                                                                                                \
+            hipLaunchKernelGGL(ipo_row_kernel<KJ>, grid, block, 0, st, x0, uv, K, keys, axes_mask, ipo_T, min_scale, max_scale, iters, inv_norm, R, T, \
+                               q, scale, state, it_begin, b1p0, b2p0, B, N, J, row_offset);                                                    \
+            break;
+        switch (k) {
+            ZEDO_IPO_ROW_CASE(1) ZEDO_IPO_ROW_CASE(2) ZEDO_IPO_ROW_CASE(3) ZEDO_IPO_ROW_CASE(4) ZEDO_IPO_ROW_CASE(5) ZEDO_IPO_ROW_CASE(6)
+            ZEDO_IPO_ROW_CASE(7) ZEDO_IPO_ROW_CASE(8) ZEDO_IPO_ROW_CASE(9) ZEDO_IPO_ROW_CASE(10) ZEDO_IPO_ROW_CASE(11) ZEDO_IPO_ROW_CASE(12)
+            ZEDO_IPO_ROW_CASE(13) ZEDO_IPO_ROW_CASE(14) ZEDO_IPO_ROW_CASE(15) ZEDO_IPO_ROW_CASE(16) ZEDO_IPO_ROW_CASE(17)
+        }
+#undef ZEDO_IPO_ROW_CASE
         return hipGetLastError();
     }
     hipLaunchKernelGGL(ipo_kernel, dim3((B + 1) / 2), dim3(64), 0, st, x0, uv, K, keys, k,

@@ -268,6 +268,31 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
     corr_fn = functools.partial(shared_corrector_update_fn, sde=sde, corrector=corrector, continuous=continuous,
                                 snr=snr, n_steps=n_steps)
 
+    def step_device(model, condition, gradient=None, denoise_x=None, t=None, t_step=None, args=None):
+        """The same predictor-corrector step with the result LEFT ON THE DEVICE: -> the tensor the public callable hands back as
+        numpy (x_mean with noise removal, else x_new).  For callers that own the loop (run/_driver.py::stepwise_loop): the
+        reference's per-step D2H + H2D round trip (:515,525 and run/opt_main.py:220) moves the values and changes no bit, so a
+        loop stepped through this entry produces the rows of the numpy surface exactly, without 2 x S synchronising copies.
+        `t` may be a Python float (no device read at all) or a tensor."""
+        with torch.no_grad():
+            x = denoise_x
+            tval = float(t)
+            if t_step is not None and t_step < 0:      # reference :499 (disabled override, kept for parity)
+                tval = 1.0
+            if fused and model_is_fusable(model):
+                import zedo_hip  # noqa: F811
+                if model.training:
+                    model.eval()
+                sched, si = loop.lookup(model, tval, t_step)
+                x_mean = x.detach().float().contiguous().clone()
+                zedo_hip.sde_step(model.hip_weights(), sched, si, x_mean)
+                return x_mean
+            vec_t = torch.ones(x.shape[0], device=x.device) * tval
+            mask = torch.zeros_like(x)
+            x1, _ = corr_fn(x, vec_t, condition, mask, model=model)
+            x_new, x_mean = pred_fn(x1, vec_t, condition, mask, model=model)
+            return x_mean if denoise else x_new
+
     def pc_sampler(model, condition, gradient=None, denoise_x=None, t=None, t_step=None, args=None):
         with torch.no_grad():
             x = denoise_x
@@ -303,4 +328,5 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
 
     stage = {}
     pc_sampler.loop_schedule = loop          # introspection for tests: hits / misses of the whole-loop schedule
+    pc_sampler.step_device = step_device     # the device-resident twin for loops owned by the driver (no per-step host copies)
     return pc_sampler

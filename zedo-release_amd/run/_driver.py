@@ -123,11 +123,16 @@ def not_fused_because(config):
     return None
 
 
-def stepwise_loop(config, model, sde, sample_poses, gt_2d, K, S, device, hypotheses=None):
+def stepwise_loop(config, model, sde, sample_poses, gt_2d, K, S, device, hypotheses=None, host_round_trip=False):
     """run/opt_main.py:166-222 as written there - one hypothesis at a time, IPO through RotOpt (one zedo_ipo_fit
-    launch), then S iterations of gradient_field_gen + sampling_fn with the host round trip the reference's
-    pc_sampler makes - for configurations outside the fused pipeline.  hypotheses = (first, count): only that
-    contiguous range of the hypothesis loop (one rank's share).  Returns rows [count*N,17,3] (h-major)."""
+    launch), then S iterations of gradient_field_gen + one sampler step - for configurations outside the fused
+    pipeline.  hypotheses = (first, count): only that contiguous range of the hypothesis loop (one rank's share).
+    Returns rows [count*N,17,3] (h-major).
+    The loop is device-resident (round 6): the sampler's `step_device` twin hands the updated rows back as a device
+    tensor and the time stamps are host floats, so no iteration synchronises or copies - the reference's pc_sampler
+    returns numpy (sampling.py:515-527) and its driver re-uploads it (run/opt_main.py:220): 2 x S blocking copies that
+    move the values and change no bit.  host_round_trip=True steps the public numpy-returning `sampling_fn` exactly as
+    the reference's driver does (the parity reference of the device-resident loop, tests/test_surface_gpu.py)."""
     from lib.algorithms.advanced import sampling
     from lib.algorithms.advanced.simple_zeroshot_opt import RotOpt, gradient_field_gen
     z = config.ZeDO
@@ -136,9 +141,12 @@ def stepwise_loop(config, model, sde, sample_poses, gt_2d, K, S, device, hypothe
                                            device=device)
     condition = torch.tensor(gt_2d[:, :, :2], device=device).float()
     conf = torch.tensor(gt_2d[:, :, 2], device=device).float()
+    zero_condition = condition * 0
     Kd = torch.tensor(K, device=device).float()
     centred = torch.tensor(sample_poses - sample_poses[:, 0:1, :], device=device).float()
     timestamp = torch.linspace(sde.T, z.sampling_eps, S, device=device)
+    t_host = timestamp.cpu().tolist()          # the same fp32 values the reference reads one by one with float(t)
+    step_device = None if host_round_trip else getattr(sampling_fn, "step_device", None)
     out = []
     h_lo, h_cnt = (0, len(sample_poses)) if hypotheses is None else hypotheses
     for sid in range(h_lo, h_lo + h_cnt):
@@ -154,6 +162,9 @@ def stepwise_loop(config, model, sde, sample_poses, gt_2d, K, S, device, hypothe
                 else:
                     g, T = gradient_field_gen(condition, denoise_x, Kd, conf=conf, returnT=True)
                 denoise_x += g
+                if step_device is not None:
+                    denoise_x = step_device(model, condition=zero_condition, gradient=g, denoise_x=denoise_x, t=t_host[i], t_step=i, args=None)
+                    continue
                 _, results = sampling_fn(model, condition=condition * 0, gradient=g, denoise_x=denoise_x,
                                          t=timestamp[i], t_step=i, args=None)
                 denoise_x = torch.as_tensor(results).to(device)

@@ -64,6 +64,7 @@ SIGNATURES = {
     "zedo_min_mpjpe": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp]),
     "zedo_pose_min": (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp]),
     "zedo_probe_mfma_peak": (_i, [_i, _vp, _vp, _vp]),
+    "zedo_probe_mfma_peak_f16": (_i, [_i, _vp, _vp, _vp]),
     "zedo_profile_start": (_i, [_i, _i]),
     "zedo_profile_stop": (_i, [_vp, _vp, _vp]),
     "zedo_profile_shader_ghz": (_d, []),
@@ -406,7 +407,16 @@ def probe_mfma_peak(iters=100000):
     return tf.value, ghz.value
 
 
-PROF_CLASSES = ("hidden_dense", "pre_dense", "post_dense_sde", "reproj")
+def probe_mfma_peak_f16(iters=400000):
+    """-> (sustained fp16-MFMA TFLOP/s, shader clock GHz): a bare v_mfma_f32_32x32x16_f16 stream on this box right now
+    (zedo_probe_mfma_peak_f16) - the attainable ceiling of the split-fp16 mode's matrix pipe under power management."""
+    _need_gpu()
+    tf, ghz = ctypes.c_double(), ctypes.c_double()
+    _check(_lib.zedo_probe_mfma_peak_f16(int(iters), ctypes.cast(ctypes.byref(tf), _vp), ctypes.cast(ctypes.byref(ghz), _vp), _stream()))
+    return tf.value, ghz.value
+
+
+PROF_CLASSES = ("hidden_dense", "pre_dense", "post_dense_sde", "reproj", "seam_post_pre")
 
 
 def profile_start(sample_every=16, max_samples=8192):
