@@ -1,6 +1,7 @@
 """GPU tests of the drop-in surface (the reference's Python callables bound to the HIP library) and of the
 fused driver, against the golden vectors captured from the reference."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -264,6 +265,10 @@ def test_reference_loop_through_the_per_step_surface(model, weights0):
     pipe = Pipeline(weights0, ZeDOConfig.h36m(OIL_iterations=S), "cuda").load(cl, d["db_2d"], d["camera_param"])
     x_fused, _ = pipe.run()
     assert torch.equal(x_surface, x_fused)
+    # the driver's loop is device-resident (round 6: sampling_fn.step_device, host-float time stamps); stepping the public
+    # numpy-returning callable with the reference's D2H / H2D round trip per iteration gives the same rows bit for bit
+    x_host = _driver.stepwise_loop(cfg, model, sde, cl, d["db_2d"].copy(), d["camera_param"], S, torch.device("cuda"), host_round_trip=True)
+    assert torch.equal(x_host, x_surface)
     # a caller stepping times of its own (not the loop's linspace) still gets the right step, via one-entry schedules
     fn = orig(cfg, sde, (N, 17, 3), lambda v: v, cfg.ZeDO.sampling_eps, device=torch.device("cuda"))
     x = x_fused[:N].clone()
@@ -462,23 +467,19 @@ def test_run_opt_main_and_inference_synthetic(tmp_path, math_mode):
     assert errs is not None and all(np.isfinite(e) for e in errs)
 
 
-@pytest.mark.parametrize("tag,flags", [("gt", ["--gt"]), ("dt", [])])
-def test_opt_main_from_files_matches_reference(tmp_path, golden, weights0, tag, flags, monkeypatch):
-    """SURVEY 8f rows 1-2: the driver fed from FILES in the reference's formats - data/h36m/h36m_test.pkl
-    (+ h36m_sh_dt_ft.pkl detections), clusters/h36m_cluster{H}.npy, a DataParallel-style checkpoint .pth -
-    against the reference's readers + loop + action-wise eval_multi on the same files
-    (tools/gen_golden.py::gen_driver_files; N=20, H=2, S=60).  Bar: 0.05 mm (BASELINE.json north_star)."""
+def _file_driver_workdir(tmp_path, weights0, clusters, hypo):
+    """A working directory laid out like the reference's repository root: data/h36m/h36m_test.pkl (+ h36m_sh_dt_ft.pkl detections),
+    clusters/h36m_cluster{H}.npy, a DataParallel-style checkpoint .pth, a config for the 20-pose asset file.  -> config path"""
     import shutil
-    import run.opt_main as om
     from lib.algorithms.advanced.model import ScoreModelFC_Adv
     from lib.algorithms.ema import ExponentialMovingAverage
     from lib.dataset import synthetic as syn
     from run._driver import load_config
-    g = golden("driver_files")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     shutil.copytree(os.path.join(root, "tests", "golden", "assets", "h36m"), tmp_path / "data" / "h36m")
-    os.makedirs(tmp_path / "clusters")
-    np.save(tmp_path / "clusters" / "h36m_cluster2.npy", g["clusters"])
+    if clusters is not None:
+        os.makedirs(tmp_path / "clusters")
+        np.save(tmp_path / "clusters" / f"h36m_cluster{hypo}.npy", clusters)
     cfg_file = tmp_path / "cfg_h36m_small.py"
     cfg_file.write_text(
         "import importlib.util\n"
@@ -498,6 +499,18 @@ def test_opt_main_from_files_matches_reference(tmp_path, golden, weights0, tag, 
     os.makedirs(tmp_path / "ckpt")
     torch.save({"model_state_dict": {"module." + k: v for k, v in model.state_dict().items()},
                 "ema": ema.state_dict(), "step": 1500}, tmp_path / "ckpt" / "checkpoint_1500.pth")
+    return cfg_file
+
+
+@pytest.mark.parametrize("tag,flags", [("gt", ["--gt"]), ("dt", [])])
+def test_opt_main_from_files_matches_reference(tmp_path, golden, weights0, tag, flags, monkeypatch):
+    """SURVEY 8f rows 1-2: the driver fed from FILES in the reference's formats - data/h36m/h36m_test.pkl
+    (+ h36m_sh_dt_ft.pkl detections), clusters/h36m_cluster{H}.npy, a DataParallel-style checkpoint .pth -
+    against the reference's readers + loop + action-wise eval_multi on the same files
+    (tools/gen_golden.py::gen_driver_files; N=20, H=2, S=60).  Bar: 0.05 mm (BASELINE.json north_star)."""
+    import run.opt_main as om
+    g = golden("driver_files")
+    cfg_file = _file_driver_workdir(tmp_path, weights0, g["clusters"], 2)
     monkeypatch.chdir(tmp_path)
     a = om.parse_args(["prog", "--config", str(cfg_file), "--ckpt_dir", "ckpt", "--ckpt_name", "checkpoint_1500.pth",
                        "--hypo", "2", "--oil_iterations", "60"] + flags)
@@ -506,6 +519,27 @@ def test_opt_main_from_files_matches_reference(tmp_path, golden, weights0, tag, 
     print(f"files[{tag}]: MPJPE {p1:.6f} vs {float(g[f'{tag}_mpjpe']):.6f} (d {d1 * 1e3:.4f} mm), "
           f"PA {p2:.6f} vs {float(g[f'{tag}_pa_mpjpe']):.6f} (d {d2 * 1e3:.4f} mm)")
     assert d1 < 5e-5 and d2 < 5e-5
+
+
+def test_opt_main_accepts_a_cluster_file_built_by_the_tool(tmp_path, weights0, monkeypatch):
+    """SURVEY 8 f2 (optional cluster builder, absent from the reference): tools/make_clusters.py turns a pose set - here the 20 poses
+    of the asset test file itself, in the H36M pickle layout - into clusters/h36m_cluster{H}.npy, and the file-driven driver runs on
+    it (H = 1 and H = 4): shape / dtype / path are what run/opt_main.py:58-65 loads, the run completes, and both protocol means come
+    out finite with PA-MPJPE <= MPJPE."""
+    import run.opt_main as om
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_clusters as mc
+    cfg_file = _file_driver_workdir(tmp_path, weights0, None, 0)
+    monkeypatch.chdir(tmp_path)
+    res = {}
+    for H in (1, 4):
+        path = mc.main([os.path.join("data", "h36m", "h36m_test.pkl"), "--hypo", str(H), "--name", "h36m", "--medoid"])
+        c = np.load(path)
+        assert path == os.path.join("clusters", f"h36m_cluster{H}.npy") and c.shape == (H, 17, 3) and c.dtype == np.float32
+        a = om.parse_args(["prog", "--config", str(cfg_file), "--ckpt_dir", "ckpt", "--ckpt_name", "checkpoint_1500.pth",
+                           "--hypo", str(H), "--oil_iterations", "60", "--gt"])
+        res[H] = om.main(a)
+        assert all(np.isfinite(v) for v in res[H]) and res[H][1] <= res[H][0] + 1e-9
 
 
 PC_GENERIC_CASES = [
@@ -552,6 +586,10 @@ def test_pc_sampler_other_sdes_and_update_rules(model, golden, monkeypatch, case
                     t=torch.tensor(t), t_step=3)
     assert isinstance(res, torch.Tensor) == bool(p[f"{tag}_res_is_tensor"])
     res = res.cpu().numpy() if isinstance(res, torch.Tensor) else res
+    # the device-resident twin the driver's loop steps (round 6): the same update rules, no host copies - bit-identical
+    monkeypatch.setattr(torch, "randn_like", DetNoise())
+    res_dev = fn.step_device(model, condition=torch.zeros(8, 17, 2, device="cuda"), denoise_x=dev(p["x"]), t=float(torch.tensor(t)), t_step=3)
+    assert res_dev.is_cuda and np.array_equal(res_dev.cpu().numpy(), res)
     scale = max(1.0, float(np.abs(p[f"{tag}_res"]).max()))
     d1, d2 = np.abs(trajs - p[f"{tag}_trajs"]).max(), np.abs(res - p[f"{tag}_res"]).max()
     print(f"pc_generic[{tag}]: max|d trajs| {d1:.2e}  max|d res| {d2:.2e}  (magnitude {scale:.2f})")

@@ -17,11 +17,52 @@ import numpy as np
 import torch
 
 
+def generic(a):
+    """a 1000-step run of a non-shipped sampler configuration at BASELINE configs[1]'s 886 rows, H = 1, before / after."""
+    from lib.algorithms.advanced.model import ScoreModelFC_Adv
+    from lib.dataset import synthetic as syn
+    from run import _driver
+    cfg = _driver.load_config(os.path.join(ROOT, "zedo-release_amd", "configs", "optim", "concat_pose_optimization_h36m.py"))
+    cfg.training.sde = a.generic
+    cfg.sampling.probability_flow = True
+    assert _driver.not_fused_because(cfg) is not None
+    N, S = a.poses, a.steps
+    cfg.ZeDO.OIL_iterations = S
+    dev = torch.device("cuda")
+    model = ScoreModelFC_Adv(cfg, 17, 3, 1024, 512, 3)
+    sd = {k: torch.tensor(v) for k, v in syn.make_weights(seed=0).items()}
+    sd["sigmas"] = torch.tensor(syn.sigmas_buffer())
+    model.load_state_dict(sd)
+    model.eval()
+    d = syn.make_poses(N, seed=101, conf_mode="uniform")
+    cl = syn.make_clusters(1, seed=17)
+    sde = _driver.make_sde(cfg)
+    out, res = {}, {}
+    for tag, rt in (("host_round_trip", True), ("device_resident", False), ("host_round_trip", True), ("device_resident", False)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x = _driver.stepwise_loop(cfg, model, sde, cl, d["db_2d"].copy(), d["camera_param"], S, dev, host_round_trip=rt)
+        torch.cuda.synchronize()
+        out.setdefault(tag, []).append(round((time.perf_counter() - t0) * 1e3, 1))
+        res[tag] = x
+    print(json.dumps(dict(config=f"training.sde = {a.generic}, euler_maruyama / none, probability flow: generic per-step route "
+                                 "(score network on the HIP path, update rule in torch element-wise operators)",
+                          poses=N, steps=S, host_threads=torch.get_num_threads(), ms_per_pass_incl_ipo=out,
+                          ms_per_step={k: round(min(v) / S, 4) for k, v in out.items()},
+                          speedup=round(min(out["host_round_trip"]) / min(out["device_resident"]), 3),
+                          bitwise_equal=bool(torch.equal(res["host_round_trip"], res["device_resident"])))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--poses", type=int, default=886)
     ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--generic", default=None, metavar="SDE",
+                    help="time run/_driver.py::stepwise_loop for a configuration OUTSIDE the fused pipeline (e.g. vpsde): the "
+                         "device-resident loop (sampling_fn.step_device) against the reference's per-step D2H/H2D round trip")
     a = ap.parse_args()
+    if a.generic:
+        return generic(a)
     from lib.algorithms.advanced import sampling
     from lib.algorithms.advanced.model import ScoreModelFC_Adv
     from lib.algorithms.advanced.simple_zeroshot_opt import gradient_field_gen

@@ -600,6 +600,7 @@ struct Net {
     // post_dense + SDE update [+ nr] of one iteration and pre_dense of the next (time-bias rows tb_next) in one launch;
     // hipErrorNotSupported: this batch shape has no seam kernel (the caller issues the two launches)
     hipError_t seam(float sa, float sc, const NextReproj &nr, const float *tb_next) const {
+        if (!seam_rows_ok(Bp)) return hipErrorNotSupported;       // before the profiler's bracket: nothing is launched, nothing is counted
         ProfScope ps(ZEDO_PROF_SEAM, st);
         if (f16()) return launch_seam16(post_args16(true, sa, sc, nullptr, nr), pre_args16(tb_next), st);
         return launch_seam(post_args(true, sa, sc, nullptr, nr), pre_args(tb_next), st);

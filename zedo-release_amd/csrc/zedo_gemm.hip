@@ -631,8 +631,7 @@ __global__ __launch_bounds__(256, 2) void seam_kernel(LayerArgs post, LayerArgs 
 // -> hipErrorNotSupported when the batch takes another post_dense shape (small batches: quarter tiles + post_reduce_kernel, 32-row
 // tiles): the caller then issues the two launches.
 hipError_t launch_seam(const LayerArgs &post, const LayerArgs &pre, hipStream_t st) {
-    // from one 64-row tile per CU up: below that the eight column tiles of pre_dense are better spread over eight workgroups
-    if (post.Mp <= 8192 || post.Mp < num_cus() * SEAM_MIN_TILES_PER_CU * 64 || post.Mp % 64 || post.Mp != pre.Mp) return hipErrorNotSupported;
+    if (!seam_rows_ok(post.Mp) || post.Mp != pre.Mp) return hipErrorNotSupported;
     if (post.N != XLD || post.K % (4 * 32 * 4) || pre.K != 2 * 32 || !pre.kzero8 || pre.N % 128) return hipErrorNotSupported;
     constexpr size_t ring_post = (size_t)4 * (64 + 64) * 32, stage_post = (size_t)2 * 32 * 64, par_post = 3 * 64;
     constexpr size_t ring_pre = (size_t)2 * (64 + 128) * 32, stage_pre = (size_t)2 * 32 * 128, par_pre = 3 * 128;

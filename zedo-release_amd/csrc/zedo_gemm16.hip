@@ -540,7 +540,7 @@ static Layer16Args rows_of16(const Layer16Args &a, int row0, int rows) {
 }
 
 hipError_t launch_seam16(const Layer16Args &post, const Layer16Args &pre, hipStream_t st) {
-    if (post.Mp <= 8192 || post.Mp < num_cus() * SEAM_MIN_TILES_PER_CU * 64 || post.Mp % 64 || post.Mp != pre.Mp) return hipErrorNotSupported;
+    if (!seam_rows_ok(post.Mp) || post.Mp != pre.Mp) return hipErrorNotSupported;
     if (post.N != XLD || post.K % (8 * 16) || !post.X || !post.xio || post.ldx < post.Mp) return hipErrorNotSupported;
     if (!pre.Xf32 || pre.K != XLD || pre.N % 128 || !pre.out || pre.out_f32 || pre.ldo < pre.Mp) return hipErrorNotSupported;
     constexpr size_t lds_post = (size_t)8 * (64 + 64) * 64 + 3 * 64 * sizeof(float);

@@ -94,6 +94,10 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st);
 // rows in one launch (zedo_gemm.hip::seam_kernel); hipErrorNotSupported when the batch takes another post_dense shape
 hipError_t launch_seam(const LayerArgs &post, const LayerArgs &pre, hipStream_t st);
 constexpr int SEAM_MIN_TILES_PER_CU = 1;   // both math modes: a seam launch needs at least this many 64-row tiles per CU
+// the batch shapes that have a seam kernel (both math modes): whole 64-row tiles, at least SEAM_MIN_TILES_PER_CU of them per CU of the
+// current device - below that the eight column tiles of pre_dense are better spread over eight workgroups, and batches of up to 8 192
+// rows take other post_dense shapes anyway
+inline bool seam_rows_ok(int Mp) { return Mp > 8192 && Mp % 64 == 0 && Mp >= num_cus() * SEAM_MIN_TILES_PER_CU * 64; }
 
 // One hidden layer on the fp16 matrix pipe (zedo_gemm16.hip): out = epilogue(X . W^T * unscale + bias), X and W in the
 // split-fp16 planes format, three 32x32x16 fp16 MFMAs (hl, lh, hh) per 16-k block, fp32 accumulation.
