@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 #define ZEDO_ABI_VERSION 5   /* 3: + zedo_reproj_degenerate, zedo_pose_min, zedo_weights_set_math / zedo_weights_get_math;
-                              * 4: + zedo_profile_bracket_ms;  5: + zedo_probe_mfma_peak_f16, ZEDO_PROF_SEAM (ZEDO_PROF_CLASSES 4 -> 5), workspace rows rounded to 64 again */
+                              * 4: + zedo_profile_bracket_ms;  5: + zedo_probe_mfma_peak_f16, workspace rows rounded to 64 again */
 
 #define ZEDO_OK 0
 #define ZEDO_E_BADARG (-1)      /* NULL pointer, non-positive size, unsupported dimension */
@@ -223,8 +223,7 @@ int zedo_pose_min(const double *d_err, int B, int N, long long row_offset, doubl
 #define ZEDO_PROF_PRE 1     /* pre_dense (+GroupNorm+SiLU) */
 #define ZEDO_PROF_POST 2    /* post_dense + SDE update */
 #define ZEDO_PROF_REPROJ 3  /* reprojection correction (stand-alone launch: first iteration of a zedo_oil_run call) */
-#define ZEDO_PROF_SEAM 4    /* post_dense + SDE update of iteration i and pre_dense of iteration i + 1 in one launch (zedo_oil_run, large batches) */
-#define ZEDO_PROF_CLASSES 5
+#define ZEDO_PROF_CLASSES 4
 int zedo_profile_start(int sample_every, int max_samples);
 /* What this box's matrix pipe sustains right now: `iters` x 16 back-to-back v_mfma_f32_32x32x2_f32 per wave on every
  * SIMD (two waves each) -> TFLOP/s, and the shader clock seen over that run.  Boxes of one pool differ by a few per

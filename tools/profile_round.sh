@@ -17,7 +17,7 @@ python3 $ROOT/tools/rocpd_summary.py $(find /tmp/zprof_kt -name '*_results.db' |
 # the opt-in split-fp16 mode of the hidden layers (alt_mode of the bench line), profiled on its own
 rocprofv3 --kernel-trace --stats -d /tmp/zprof_kt16 -o kt -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-mode --math f16x3 > $ROOT/gpurun_out/prof_${TAG}_bench_f16x3.log 2>&1
 python3 $ROOT/tools/rocpd_summary.py $(find /tmp/zprof_kt16 -name '*_results.db' | head -1) > $ROOT/gpurun_out/kernel_stats_${TAG}_f16x3.txt
-ARGS="--steps 1 --warmup 0 --oil 40 --no-cpu-baseline --no-alt-mode"
+ARGS="--steps 1 --warmup 0 --oil 40 --no-cpu-baseline --no-alt-mode --no-geometry"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/zprof_f -o f -- python3 $ROOT/bench.py $ARGS > $ROOT/gpurun_out/pmc_${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/zprof_w -o w -- python3 $ROOT/bench.py $ARGS > $ROOT/gpurun_out/pmc_${TAG}_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -d /tmp/zprof_s -o s -- python3 $ROOT/bench.py $ARGS > $ROOT/gpurun_out/pmc_${TAG}_sq.log 2>&1

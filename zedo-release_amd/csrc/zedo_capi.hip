@@ -503,8 +503,8 @@ struct NextReproj {          // reprojection of the next loop iteration, fused i
 };
 
 // The six dense layers of one score-network evaluation (model.py:264-291) as three pieces - pre_dense, the four hidden layers,
-// post_dense - so that zedo_oil_run can put post_dense of iteration i and pre_dense of iteration i + 1 into ONE launch (the seam
-// kernels of zedo_gemm.hip / zedo_gemm16.hip).  h / h1: activations [rows][1024] fp32 (exact-fp32 mode) or split-fp16 planes
+// post_dense (round 6 measured post_dense of iteration i and pre_dense of iteration i + 1 in ONE launch: bit-identical, slower in both
+// math modes, not adopted - profiles/seam_r06.txt).  h / h1: activations [rows][1024] fp32 (exact-fp32 mode) or split-fp16 planes
 // (ZEDO_MATH_F16X3: the same 4 bytes per element, k-block-major with `ld` rows per k block); the pose state xpad, the time-bias rows
 // and the SDE / reprojection epilogue are fp32 in both modes.
 struct Net {
@@ -597,14 +597,6 @@ struct Net {
         if (f16()) return launch_layer16(post_args16(sde, sa, sc, eps_out, nr), sde ? EPI_SDE : EPI_BIAS, st);
         return launch_layer(post_args(sde, sa, sc, eps_out, nr), sde ? EPI_SDE : EPI_BIAS, st);
     }
-    // post_dense + SDE update [+ nr] of one iteration and pre_dense of the next (time-bias rows tb_next) in one launch;
-    // hipErrorNotSupported: this batch shape has no seam kernel (the caller issues the two launches)
-    hipError_t seam(float sa, float sc, const NextReproj &nr, const float *tb_next) const {
-        if (!seam_rows_ok(Bp)) return hipErrorNotSupported;       // before the profiler's bracket: nothing is launched, nothing is counted
-        ProfScope ps(ZEDO_PROF_SEAM, st);
-        if (f16()) return launch_seam16(post_args16(true, sa, sc, nullptr, nr), pre_args16(tb_next), st);
-        return launch_seam(post_args(true, sa, sc, nullptr, nr), pre_args(tb_next), st);
-    }
     hipError_t all(const float *tb, bool sde, float sa, float sc, float *eps_out, const NextReproj &nr = NextReproj()) const {
         hipError_t e = pre(tb);
         if (e == hipSuccess) e = hidden(tb);
@@ -672,13 +664,8 @@ extern "C" int zedo_oil_run(const zedo_weights_t *w, const zedo_schedule_t *s, f
         // correction of every later iteration i+1 rides in the epilogue of iteration i's post_dense launch
         // (ZEDO_UNFUSED_REPROJ=1: one launch per iteration, the A/B and parity reference)
         static const bool unfused = getenv("ZEDO_UNFUSED_REPROJ") != nullptr;
-        // post_dense of iteration i and pre_dense of iteration i + 1 share a launch wherever the batch shape has a seam kernel
-        // (round 6; ZEDO_NO_SEAM=1: two launches, the A/B and bitwise reference of the seam)
-        static const bool no_seam = getenv("ZEDO_NO_SEAM") != nullptr;
         const Net net{w, k.xpad, k.h, k.h1, Bp, (int)k.rows, st};
-        bool pre_done = false;             // pre_dense of iteration i was issued by iteration i - 1's seam launch
         for (int i = step_begin; i < step_end; ++i) {
-            const float *tb = s->d_tbias + (size_t)i * NLAYER * HID;
             if (i == step_begin || unfused) {
                 ProfScope ps(ZEDO_PROF_REPROJ, st);
                 HIPCHK(launch_reproj_step_padded(k.xpad, d_geom, d_T + r0 * 3, i >= switch_step, Bc, N,
@@ -690,15 +677,7 @@ extern "C" int zedo_oil_run(const zedo_weights_t *w, const zedo_schedule_t *s, f
                 nr.row0 = row_offset + (long long)r0;
             }
             // sampling_fn(...) (run/opt_main.py:210-218) -> x = a_i x + c_i eps(x, t_i)  [+ the next correction]
-            if (!pre_done) HIPCHK(net.pre(tb));
-            HIPCHK(net.hidden(tb));
-            pre_done = false;
-            if (i + 1 < step_end && !unfused && !no_seam) {
-                const hipError_t e = net.seam(s->a[i], s->c[i], nr, tb + (size_t)NLAYER * HID);
-                if (e == hipSuccess) { pre_done = true; continue; }
-                if (e != hipErrorNotSupported) return (int)e;
-            }
-            HIPCHK(net.post(true, s->a[i], s->c[i], nullptr, nr));
+            HIPCHK(net.all(s->d_tbias + (size_t)i * NLAYER * HID, true, s->a[i], s->c[i], nullptr, nr));
         }
         HIPCHK(launch_unpack_rows(k.xpad, d_x + r0 * w->J3, Bc, w->J3, st));
     }

@@ -606,44 +606,6 @@ hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st) {
     return hipErrorInvalidValue;
 }
 
-// ---- the seam of two loop iterations in ONE launch (round 6) -----------------------------------------------------------
-// post_dense of iteration i (+ SDE update + reprojection correction of iteration i + 1) and pre_dense (+ GroupNorm + SiLU) of
-// iteration i + 1 touch the same 64 pose rows: a workgroup runs post_dense's 64x64 tile (K summed as four quarter chains, as in
-// every other shape), leaves the updated rows in the pose state, and goes straight on to the eight 64x128 column tiles of
-// pre_dense on those rows - the SAME layer_tile code as the two separate launches (same products, same order: bit-identical),
-// one launch instead of two, and the 208 MB read of post_dense's activations overlaps the 208 MB pre_dense writes (different
-// workgroups are in different phases).  The pose rows reach phase B's LDS-DMA through this CU's vector L1 / the L2: they were
-// stored by this very workgroup, every wave waits for its stores (vmcnt) before the barrier, and a workgroup's waves share one L1.
-// pre_dense writes the activation rows post_dense has just read (in place, as the two launches do): a workgroup's phase A has
-// consumed its 64 rows completely before its phase B writes them, and no other workgroup touches them.
-__global__ __launch_bounds__(256, 2) void seam_kernel(LayerArgs post, LayerArgs pre) {
-    const int m0 = (int)blockIdx.x * 64;
-    layer_tile<64, 64, 2, 2, EPI_SDE, 4, 32, SCHED_THIN, 0, 4>(post, m0, 0, m0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores of the updated pose rows have completed
-    __syncthreads();                                       // ... every wave's: the rows are phase B's X operand; the stage is free
-    const int ncol = pre.N / 128;
-    for (int c = 0; c < ncol; ++c) {
-        layer_tile<64, 128, 2, 2, EPI_GN_SILU, 2, 32, SCHED_THIN, 1, 1>(pre, m0, c * 128, m0);
-        __syncthreads();                                   // the tile's stage and parameter block become the next tile's ring
-    }
-}
-
-// -> hipErrorNotSupported when the batch takes another post_dense shape (small batches: quarter tiles + post_reduce_kernel, 32-row
-// tiles): the caller then issues the two launches.
-hipError_t launch_seam(const LayerArgs &post, const LayerArgs &pre, hipStream_t st) {
-    if (!seam_rows_ok(post.Mp) || post.Mp != pre.Mp) return hipErrorNotSupported;
-    if (post.N != XLD || post.K % (4 * 32 * 4) || pre.K != 2 * 32 || !pre.kzero8 || pre.N % 128) return hipErrorNotSupported;
-    constexpr size_t ring_post = (size_t)4 * (64 + 64) * 32, stage_post = (size_t)2 * 32 * 64, par_post = 3 * 64;
-    constexpr size_t ring_pre = (size_t)2 * (64 + 128) * 32, stage_pre = (size_t)2 * 32 * 128, par_pre = 3 * 128;
-    constexpr size_t lds_post = (ring_post > stage_post ? ring_post : stage_post) + par_post;
-    constexpr size_t lds_pre = (ring_pre > stage_pre ? ring_pre : stage_pre) + par_pre;
-    constexpr size_t lds = (lds_post > lds_pre ? lds_post : lds_pre) * sizeof(float);
-    static std::atomic<bool> attr_done[MAX_DEVICES];
-    if (hipError_t e = allow_lds(reinterpret_cast<const void *>(seam_kernel), lds, attr_done); e != hipSuccess) return e;
-    hipLaunchKernelGGL(seam_kernel, dim3(post.Mp / 64), dim3(256), lds, st, post, pre);
-    return hipGetLastError();
-}
-
 // ---- diagnostic: what this box's matrix pipe sustains right now (clock / power state differ box to box) ----------
 __global__ __launch_bounds__(256) void mfma_probe_kernel(float *out, int iters, long long *clk) {
     f32x16 acc[4];

@@ -485,22 +485,6 @@ __global__ __launch_bounds__(256, 4) void layer16_small_kernel(Layer16Args a) {
     layer16_body<64, 64, 2, 2, EPI, 4, 0>(a, blockIdx.x, gridDim.x);
 }
 
-// The seam of two loop iterations in one launch (round 6; see seam_kernel in zedo_gemm.hip): post_dense's 64x64 tile of iteration i
-// (SDE update + the next reprojection on the fp32 pose rows), then the eight 64x128 column tiles of iteration i + 1's pre_dense on
-// those rows - the same layer16_tile code as the two launches, bit-identical.  The pose rows are re-read as fp32 from the pose
-// state (XF32): this workgroup stored them, waits for the stores and shares one L1.
-__global__ __launch_bounds__(256, 2) void seam16_kernel(Layer16Args post, Layer16Args pre) {
-    const int m0 = (int)blockIdx.x * 64;
-    layer16_tile<64, 64, 2, 2, EPI_SDE, 8, 0>(post, m0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int ncol = pre.N / 128;
-    for (int c = 0; c < ncol; ++c) {
-        layer16_tile<64, 128, 2, 2, EPI_GN_SILU, 4, 1>(pre, m0, c * 128);
-        __syncthreads();
-    }
-}
-
 #ifdef ZEDO_UBENCH      // round 5's tile ping-pong experiment (not part of the library): see the file
 #include "../../tools/ubench/zedo_gemm16_tp.inc"
 #endif
@@ -537,19 +521,6 @@ static Layer16Args rows_of16(const Layer16Args &a, int row0, int rows) {
     if (a.res) b.res = a.res + (size_t)row0 * 32;
     b.Mp = rows;
     return b;
-}
-
-hipError_t launch_seam16(const Layer16Args &post, const Layer16Args &pre, hipStream_t st) {
-    if (!seam_rows_ok(post.Mp) || post.Mp != pre.Mp) return hipErrorNotSupported;
-    if (post.N != XLD || post.K % (8 * 16) || !post.X || !post.xio || post.ldx < post.Mp) return hipErrorNotSupported;
-    if (!pre.Xf32 || pre.K != XLD || pre.N % 128 || !pre.out || pre.out_f32 || pre.ldo < pre.Mp) return hipErrorNotSupported;
-    constexpr size_t lds_post = (size_t)8 * (64 + 64) * 64 + 3 * 64 * sizeof(float);
-    constexpr size_t lds_pre = (size_t)4 * (128 + 64) * 64 + 3 * 128 * sizeof(float);
-    constexpr size_t lds = lds_post > lds_pre ? lds_post : lds_pre;
-    static std::atomic<bool> done[MAX_DEVICES16];
-    if (hipError_t e = allow_lds(reinterpret_cast<const void *>(seam16_kernel), lds, done); e != hipSuccess) return e;
-    hipLaunchKernelGGL(seam16_kernel, dim3(post.Mp / 64), dim3(256), lds, st, post, pre);
-    return hipGetLastError();
 }
 
 hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st) {

@@ -90,14 +90,6 @@ struct LayerArgs {
 constexpr int POST_SPLIT_ROWS = 2048;     // measured: 886 rows 22.7 -> 16.3 us per step, 4 096 rows equal, 6 400 rows 22.8 -> 25.7
 
 hipError_t launch_layer(const LayerArgs &a, int epilogue, hipStream_t st);
-// post_dense (EPI_SDE, with its optional fused reprojection) of one loop iteration and pre_dense (EPI_GN_SILU) of the next on the same
-// rows in one launch (zedo_gemm.hip::seam_kernel); hipErrorNotSupported when the batch takes another post_dense shape
-hipError_t launch_seam(const LayerArgs &post, const LayerArgs &pre, hipStream_t st);
-constexpr int SEAM_MIN_TILES_PER_CU = 1;   // both math modes: a seam launch needs at least this many 64-row tiles per CU
-// the batch shapes that have a seam kernel (both math modes): whole 64-row tiles, at least SEAM_MIN_TILES_PER_CU of them per CU of the
-// current device - below that the eight column tiles of pre_dense are better spread over eight workgroups, and batches of up to 8 192
-// rows take other post_dense shapes anyway
-inline bool seam_rows_ok(int Mp) { return Mp > 8192 && Mp % 64 == 0 && Mp >= num_cus() * SEAM_MIN_TILES_PER_CU * 64; }
 
 // One hidden layer on the fp16 matrix pipe (zedo_gemm16.hip): out = epilogue(X . W^T * unscale + bias), X and W in the
 // split-fp16 planes format, three 32x32x16 fp16 MFMAs (hl, lh, hh) per 16-k block, fp32 accumulation.
@@ -125,8 +117,6 @@ struct Layer16Args {
     long long rp_row0;
 };
 hipError_t launch_layer16(const Layer16Args &a, int epilogue, hipStream_t st);
-// post_dense (EPI_SDE) of one loop iteration + pre_dense of the next in one launch, split-fp16 mode (zedo_gemm16.hip); hipErrorNotSupported as launch_seam
-hipError_t launch_seam16(const Layer16Args &post, const Layer16Args &pre, hipStream_t st);
 // fp32 [rows][cols] (row stride ld floats) * scale -> planes [cols/16][ldr][2][16] (k-block-major; ldr >= rows); cols % 16 == 0
 hipError_t launch_split_planes(const float *src, int rows, int cols, int ld, float scale, uint16_t *dst, int ldr, hipStream_t st);
 hipError_t probe_mfma_peak(int iters, double *tflops, double *shader_ghz, hipStream_t st, bool f16 = false);

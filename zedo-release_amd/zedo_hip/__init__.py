@@ -416,7 +416,7 @@ def probe_mfma_peak_f16(iters=400000):
     return tf.value, ghz.value
 
 
-PROF_CLASSES = ("hidden_dense", "pre_dense", "post_dense_sde", "reproj", "seam_post_pre")
+PROF_CLASSES = ("hidden_dense", "pre_dense", "post_dense_sde", "reproj")
 
 
 def profile_start(sample_every=16, max_samples=8192):
