@@ -488,6 +488,42 @@ def test_min_mpjpe_nan_hypothesis_poisons_the_pose_like_numpy(zh, golden):
         assert best_h[3].item() == 2 and best_h[7].item() == 1
 
 
+def test_selection_staged_kernel_is_bitwise_the_lane_per_row_kernel(zh):
+    """Round 6: for J = 17 the per-row error kernel stages the 64 rows of a wave (one contiguous piece of the pose tensor, coalesced
+    16-byte loads) and their ground-truth poses through the LDS; the arithmetic per row is the old statement sequence.  A pose tensor
+    whose base is not 16-byte aligned takes the old one-lane-per-row kernel: the same rows through both must agree BIT FOR BIT - errors
+    of every row, per-pose minimum, arg-min - for P1 and P2, on a shard (row_offset) whose tiles wrap around the N poses several
+    times, with a ragged last tile and NaN hypotheses."""
+    rng = np.random.default_rng(66)
+    N, H, off = 23, 211, 17
+    B = N * H - off - 5
+    x = (0.3 * rng.standard_normal((B, 17, 3))).astype(np.float32)
+    x[5, 3, 1] = np.nan
+    x[700:703] = np.nan
+    gt = dev(0.3 * rng.standard_normal((N, 17, 3)), torch.float64)
+    xa = dev(x)
+    buf = torch.empty(B * 51 + 1, dtype=torch.float32, device="cuda")
+    xb = buf[1:].view(B, 17, 3)
+    xb.copy_(xa)
+    assert xa.data_ptr() % 16 == 0 and xb.data_ptr() % 16 == 4 and xb.is_contiguous()
+    bits = lambda t: t.view(torch.int64) if t.dtype == torch.float64 else t
+    for p2 in (False, True):
+        a = zh.min_mpjpe(xa, gt, N, procrustes=p2, row_offset=off)
+        b = zh.min_mpjpe(xb, gt, N, procrustes=p2, row_offset=off)
+        for ta, tb in zip(a, b):
+            assert torch.equal(bits(ta), bits(tb))
+        assert int(torch.isnan(a[0]).sum()) == 4 and bool(torch.isfinite(a[0][~torch.isnan(a[0])]).all())
+        # the per-pose minimum against numpy on the row errors (np.amin / np.argmin semantics incl. NaN), rows h * N + n - off
+        e = np.full((H * N,), np.inf)
+        e[off:off + B] = a[0].cpu().numpy()
+        e = e.reshape(H, N)
+        held = np.zeros((H * N,), bool); held[off:off + B] = True; held = held.reshape(H, N)
+        for n in range(N):
+            col = np.where(held[:, n], e[:, n], np.inf)
+            want_h = int(np.argmin(col)) if not np.isnan(col).any() else int(np.flatnonzero(np.isnan(col))[0])
+            assert int(a[2][n]) == want_h and (np.isnan(col[want_h]) and np.isnan(float(a[1][n])) or float(a[1][n]) == col[want_h])
+
+
 @pytest.mark.parametrize("B", [1300, 2304, 4096, 5000, 7000, 8500, 10000, 16384, 18000, 22000])
 def test_score_network_every_launch_shape(zh, W, weights0, B):
     """Row counts that take each tile-selection branch of the dense layers - exact fp32: 32 / 64 / 128-row tiles chosen by the

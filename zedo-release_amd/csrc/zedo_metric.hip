@@ -1,7 +1,7 @@
 // Hypothesis selection for gfx950: per-(hypothesis,pose) MPJPE / Procrustes-aligned MPJPE in fp64 and the
 // per-pose minimum over hypotheses (reference lib/dataset/h36m.py:394-417, lib/dataset/pw3d.py:302-331,
-// lib/utils/transforms.py:42-127).  One lane per row for the errors; one wavefront per pose for the
-// arg-min (lanes stride over hypotheses, butterfly reduction with __shfl_xor).
+// lib/utils/transforms.py:42-127).  One lane per row for the errors, the rows of a wave staged through the LDS
+// with coalesced loads; one lane per pose for the arg-min (coalesced reads of one hypothesis' errors at a time).
 #include "zedo_internal.h"
 
 namespace zedo {
@@ -63,13 +63,11 @@ __device__ void polar_from_svd(double M[3][3], double R[3][3], double &strace) {
         for (int j = 0; j < 3; ++j) R[i][j] = V[i][0] * U[j][0] + V[i][1] * U[j][1] + V[i][2] * U[j][2];
 }
 
-__global__ void row_error_kernel(const float *__restrict__ pred, const double *__restrict__ gt, int B, int N, int J,
-                                 long long row_offset, int procrustes, double *__restrict__ err) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const int n = (int)((row_offset + b) % N);
-    const float *p = pred + (size_t)b * J * 3;
-    const double *g = gt + (size_t)n * J * 3;
+// Error of one row from its staged operands: p = the row's J*3 fp32 coordinates, g = its pose's J*3 fp64 ground-truth coordinates
+// (both register / LDS resident: every access below is a plain indexed read).  The statements - and therefore every rounding - are the
+// ones of rounds 1-5's one-lane-per-row kernel; only where the operands come from has changed.
+template <class P, class G>
+__device__ __forceinline__ double row_error(const P &p, const G &g, int J, int procrustes) {
     double e = 0.0;
     if (!procrustes) {
         for (int j = 0; j < J; ++j) {
@@ -77,8 +75,7 @@ __global__ void row_error_kernel(const float *__restrict__ pred, const double *_
                          dz = (double)p[3 * j + 2] - g[3 * j + 2];
             e += sqrt(dx * dx + dy * dy + dz * dz);
         }
-        err[b] = e / J;
-        return;
+        return e / J;
     }
     // procrustes(A = gt, B = pred, scaling=True, reflection='best').Z  (transforms.py:42-127)
     double ab[3] = {0, 0, 0}, bb[3] = {0, 0, 0};
@@ -105,7 +102,41 @@ __global__ void row_error_kernel(const float *__restrict__ pred, const double *_
         const double dx = z[0] - g[3 * j], dy = z[1] - g[3 * j + 1], dz = z[2] - g[3 * j + 2];
         e += sqrt(dx * dx + dy * dy + dz * dz);
     }
-    err[b] = e / J;
+    return e / J;
+}
+
+// Any joint count: one lane per row straight from global memory (rows are J*12 bytes apart: every load instruction touches 64 cache lines).
+__global__ void row_error_kernel(const float *__restrict__ pred, const double *__restrict__ gt, int B, int N, int J,
+                                 long long row_offset, int procrustes, double *__restrict__ err) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n = (int)((row_offset + b) % N);
+    err[b] = row_error(pred + (size_t)b * J * 3, gt + (size_t)n * J * 3, J, procrustes);
+}
+
+// J = 17 (every dataset of the path), round 6: the 64 rows of a wave arrive as ONE contiguous 13 KB piece of the pose tensor, fetched with
+// coalesced 16-byte loads (a lane's own row would be 204 bytes from its neighbour's: 64 cache lines per load instruction, 427 GB/s
+// at 3.5 M rows), and the rows' ground-truth poses - consecutive poses n = (row_offset + b) mod N, 408 bytes each - with coalesced
+// 8-byte loads; both land in the LDS ([row][51], odd row stride: a lane reading its own row is bank-conflict free), all loads of the
+// tile in flight at once; then one lane per row as before.
+constexpr int RE_ROWS = 64, RE_D = 17 * 3;
+__global__ __launch_bounds__(RE_ROWS) void row_error17_kernel(const float *__restrict__ pred, const double *__restrict__ gt, int B, int N,
+                                                               long long row_offset, int procrustes, double *__restrict__ err) {
+    __shared__ __attribute__((aligned(16))) float sp[RE_ROWS * RE_D];
+    __shared__ double sg[RE_ROWS * RE_D];
+    const int tid = threadIdx.x, b0 = blockIdx.x * RE_ROWS;
+    const int rows = min(RE_ROWS, B - b0);
+    const int nf = rows * RE_D;                                   // floats of this tile (the last tile of a batch is short)
+    const float *src = pred + (size_t)b0 * RE_D;                  // 16-byte aligned: b0 * 204 bytes, b0 a multiple of 64
+    for (int c = tid; c * 4 + 3 < nf; c += RE_ROWS) *reinterpret_cast<f32x4 *>(sp + c * 4) = *reinterpret_cast<const f32x4 *>(src + c * 4);
+    if (tid < (nf & 3)) sp[(nf & ~3) + tid] = src[(nf & ~3) + tid];
+    const long long g0 = row_offset + b0;
+    for (int q = tid; q < nf; q += RE_ROWS) {
+        const int r = q / RE_D, k = q - r * RE_D;
+        sg[q] = gt[(size_t)((g0 + r) % N) * RE_D + k];
+    }
+    __syncthreads();
+    if (tid < rows) err[b0 + tid] = row_error(sp + tid * RE_D, sg + tid * RE_D, 17, procrustes);
 }
 
 // np.amin / np.argmin order: NaN is smaller than everything (a diverged hypothesis poisons the pose, and the first
@@ -122,41 +153,41 @@ __device__ __forceinline__ bool min_takes(double ov, int oh, double v, int h) {
 #endif
 }
 
-// one wavefront per pose: min / first arg-min (np.argmin tie rule) over the hypotheses held locally
+// One lane per pose: min / first arg-min (np.argmin tie rule) over the hypotheses held locally, walked in ascending order - the 64 lanes
+// of a wave read 64 consecutive poses of one hypothesis, 512 contiguous bytes per load (round 6; rounds 1-5 gave a pose to a wavefront whose
+// lanes strode over the hypotheses N * 8 bytes apart).  min_takes is a strict total order on (value, hypothesis): the minimum does not
+// depend on the order in which the candidates are visited.
 __global__ void pose_min_kernel(const double *__restrict__ err, int B, int N, long long row_offset,
                                 double *__restrict__ best, int *__restrict__ best_h) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     // global rows of pose n: n, n+N, n+2N, ... ; local index = global - row_offset
     long long h0 = (row_offset - n + N - 1) / N;     // first hypothesis with h*N + n >= row_offset
     if (row_offset <= n) h0 = 0;
     double e = __builtin_huge_val();
     int hi = -1;
-    for (long long h = h0 + lane;; h += 64) {
+    for (long long h = h0;; ++h) {
         const long long loc = h * N + n - row_offset;
         if (loc >= B) break;
         const double v = err[loc];
         if (min_takes(v, (int)h, e, hi)) { e = v; hi = (int)h; }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double oe = __shfl_xor(e, off);
-        const int oh = __shfl_xor(hi, off);
-        if (min_takes(oe, oh, e, hi)) { e = oe; hi = oh; }
-    }
-    if (lane == 0) { best[n] = (hi >= 0) ? e : __builtin_huge_val(); best_h[n] = hi; }
+    best[n] = (hi >= 0) ? e : __builtin_huge_val();
+    best_h[n] = hi;
 }
 
 hipError_t launch_pose_min(const double *err, int B, int N, long long row_offset, double *best, int *best_h, hipStream_t st) {
-    hipLaunchKernelGGL(pose_min_kernel, dim3((N + 3) / 4), dim3(256), 0, st, err, B, N, row_offset, best, best_h);
+    hipLaunchKernelGGL(pose_min_kernel, dim3((N + 127) / 128), dim3(128), 0, st, err, B, N, row_offset, best, best_h);
     return hipGetLastError();
 }
 
 hipError_t launch_min_mpjpe(const float *pred, const double *gt, int B, int N, int J, long long row_offset,
                             int procrustes, double *err, double *best, int *best_h, hipStream_t st) {
-    hipLaunchKernelGGL(row_error_kernel, dim3((B + 127) / 128), dim3(128), 0, st, pred, gt, B, N, J, row_offset,
-                       procrustes, err);
+    // (the staged kernel fetches the pose tensor with 16-byte loads: a row pointer that is not 16-byte aligned takes the generic kernel)
+    if (J == 17 && (reinterpret_cast<uintptr_t>(pred) & 15) == 0)
+        hipLaunchKernelGGL(row_error17_kernel, dim3((B + RE_ROWS - 1) / RE_ROWS), dim3(RE_ROWS), 0, st, pred, gt, B, N, row_offset, procrustes, err);
+    else
+        hipLaunchKernelGGL(row_error_kernel, dim3((B + 127) / 128), dim3(128), 0, st, pred, gt, B, N, J, row_offset, procrustes, err);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_pose_min(err, B, N, row_offset, best, best_h, st);
