@@ -1,7 +1,8 @@
 // Hypothesis selection for gfx950: per-(hypothesis,pose) MPJPE / Procrustes-aligned MPJPE in fp64 and the
 // per-pose minimum over hypotheses (reference lib/dataset/h36m.py:394-417, lib/dataset/pw3d.py:302-331,
 // lib/utils/transforms.py:42-127).  One lane per row for the errors, the rows of a wave staged through the LDS
-// with coalesced loads; one lane per pose for the arg-min (coalesced reads of one hypothesis' errors at a time).
+// with coalesced loads; the arg-min with one wavefront per pose (few poses) or one lane per pose (many: coalesced
+// reads of one hypothesis' errors at a time).
 #include "zedo_internal.h"
 
 namespace zedo {
@@ -130,10 +131,16 @@ __global__ __launch_bounds__(RE_ROWS) void row_error17_kernel(const float *__res
     const float *src = pred + (size_t)b0 * RE_D;                  // 16-byte aligned: b0 * 204 bytes, b0 a multiple of 64
     for (int c = tid; c * 4 + 3 < nf; c += RE_ROWS) *reinterpret_cast<f32x4 *>(sp + c * 4) = *reinterpret_cast<const f32x4 *>(src + c * 4);
     if (tid < (nf & 3)) sp[(nf & ~3) + tid] = src[(nf & ~3) + tid];
-    const long long g0 = row_offset + b0;
-    for (int q = tid; q < nf; q += RE_ROWS) {
-        const int r = q / RE_D, k = q - r * RE_D;
-        sg[q] = gt[(size_t)((g0 + r) % N) * RE_D + k];
+    // ground truth of row r: pose n_r = (row_offset + b0 + r) mod N - consecutive poses, wrapping to 0 behind N - 1 (several times in one
+    // tile when N < 64): the pose index is wave-uniform and advances by scalar increment / compare, no division per element; lanes 0..50
+    // fetch the pose's 51 doubles (408 contiguous bytes) per row
+    int n = (int)((row_offset + b0) % N);
+    if (tid < RE_D) {
+#pragma unroll 16
+        for (int r = 0; r < rows; ++r) {       // (unrolled: sixteen independent loads in flight per lane)
+            sg[r * RE_D + tid] = gt[(size_t)n * RE_D + tid];
+            n = (n + 1 == N) ? 0 : n + 1;
+        }
     }
     __syncthreads();
     if (tid < rows) err[b0 + tid] = row_error(sp + tid * RE_D, sg + tid * RE_D, 17, procrustes);
@@ -153,16 +160,43 @@ __device__ __forceinline__ bool min_takes(double ov, int oh, double v, int h) {
 #endif
 }
 
-// One lane per pose: min / first arg-min (np.argmin tie rule) over the hypotheses held locally, walked in ascending order - the 64 lanes
-// of a wave read 64 consecutive poses of one hypothesis, 512 contiguous bytes per load (round 6; rounds 1-5 gave a pose to a wavefront whose
-// lanes strode over the hypotheses N * 8 bytes apart).  min_takes is a strict total order on (value, hypothesis): the minimum does not
-// depend on the order in which the candidates are visited.
+// min / first arg-min (np.argmin tie rule) over the hypotheses held locally.  min_takes is a strict total order on (value, hypothesis):
+// the minimum does not depend on the order in which the candidates are visited, so both kernels below return the same bits.
+// Few poses (N below POSE_MIN_LANE_N): one WAVEFRONT per pose, lanes stride over the hypotheses (N * 8 bytes apart: one cache line per
+// lane), butterfly reduction - the parallelism is across hypotheses, a pass is one load deep.
+__global__ void pose_min_wave_kernel(const double *__restrict__ err, int B, int N, long long row_offset,
+                                     double *__restrict__ best, int *__restrict__ best_h) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    // global rows of pose n: n, n+N, n+2N, ... ; local index = global - row_offset
+    long long h0 = (row_offset - n + N - 1) / N;     // first hypothesis with h*N + n >= row_offset
+    if (row_offset <= n) h0 = 0;
+    double e = __builtin_huge_val();
+    int hi = -1;
+    for (long long h = h0 + lane;; h += 64) {
+        const long long loc = h * N + n - row_offset;
+        if (loc >= B) break;
+        const double v = err[loc];
+        if (min_takes(v, (int)h, e, hi)) { e = v; hi = (int)h; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double oe = __shfl_xor(e, off);
+        const int oh = __shfl_xor(hi, off);
+        if (min_takes(oe, oh, e, hi)) { e = oe; hi = oh; }
+    }
+    if (lane == 0) { best[n] = (hi >= 0) ? e : __builtin_huge_val(); best_h[n] = hi; }
+}
+
+// Many poses (round 6): one LANE per pose, hypotheses walked in ascending order - the 64 lanes of a wave read 64 consecutive poses of one
+// hypothesis, 512 contiguous bytes per load, where the wave-per-pose kernel touches H cache lines per pose.
+constexpr int POSE_MIN_LANE_N = 8192;
 __global__ void pose_min_kernel(const double *__restrict__ err, int B, int N, long long row_offset,
                                 double *__restrict__ best, int *__restrict__ best_h) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    // global rows of pose n: n, n+N, n+2N, ... ; local index = global - row_offset
-    long long h0 = (row_offset - n + N - 1) / N;     // first hypothesis with h*N + n >= row_offset
+    long long h0 = (row_offset - n + N - 1) / N;
     if (row_offset <= n) h0 = 0;
     double e = __builtin_huge_val();
     int hi = -1;
@@ -177,7 +211,8 @@ __global__ void pose_min_kernel(const double *__restrict__ err, int B, int N, lo
 }
 
 hipError_t launch_pose_min(const double *err, int B, int N, long long row_offset, double *best, int *best_h, hipStream_t st) {
-    hipLaunchKernelGGL(pose_min_kernel, dim3((N + 127) / 128), dim3(128), 0, st, err, B, N, row_offset, best, best_h);
+    if (N >= POSE_MIN_LANE_N) hipLaunchKernelGGL(pose_min_kernel, dim3((N + 127) / 128), dim3(128), 0, st, err, B, N, row_offset, best, best_h);
+    else hipLaunchKernelGGL(pose_min_wave_kernel, dim3((N + 3) / 4), dim3(256), 0, st, err, B, N, row_offset, best, best_h);
     return hipGetLastError();
 }
 
