@@ -38,12 +38,17 @@ def build(flag):
                    stdout=subprocess.DEVNULL)
 
 
-def run_suite():
+def run_suite(modes=None):
+    """modes: None = both arithmetic modes of the suite (tests/conftest.py), "f32" / "f16x3" = that one only (ZEDO_TEST_MATH)."""
     t0 = time.time()
     cmd = [sys.executable, "-m", "pytest", "tests", "-m", "gpu", "-q", "--no-header", "-rf", "-p", "no:cacheprovider"]
     if os.environ.get("ZEDO_MUT_DESELECT"):          # e.g. the three-minute end-to-end ensembles: "not lie_inside and not pooled"
         cmd += ["-k", os.environ["ZEDO_MUT_DESELECT"]]
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
+    env = dict(os.environ)
+    env.pop("ZEDO_TEST_MATH", None)
+    if modes:
+        env["ZEDO_TEST_MATH"] = modes
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, env=env)
     out = r.stdout + r.stderr
     failed = sorted(set(re.findall(r"^FAILED (\S+)", out, re.M)))
     m = re.search(r"(\d+) passed", out)
@@ -60,8 +65,13 @@ def main():
             if only and flag != only:
                 continue
             build(flag)
-            failed, passed, dt, out = run_suite()
-            rows.append((flag, what, failed, passed, dt))
+            # mutations of code both modes share are hunted in the exact-fp32 cells (half the suite time); the two mutations of the
+            # split-fp16 kernels run BOTH modes: they must turn f16x3 cells red and leave every f32 cell green
+            f16_only = flag.startswith("ZEDO_MUT_F16_")
+            failed, passed, dt, out = run_suite(None if f16_only else "f32")
+            if f16_only and any("[f32" in t for t in failed):
+                ok = False
+            rows.append((flag, what + (" [both modes]" if f16_only else " [f32 cells]"), failed, passed, dt))
             ok &= len(failed) > 0
             print(f"{flag}: {len(failed)} red / {passed} green in {dt:.0f} s", flush=True)
     finally:
