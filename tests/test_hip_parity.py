@@ -524,6 +524,56 @@ def test_selection_staged_kernel_is_bitwise_the_lane_per_row_kernel(zh):
             assert int(a[2][n]) == want_h and (np.isnan(col[want_h]) and np.isnan(float(a[1][n])) or float(a[1][n]) == col[want_h])
 
 
+def test_selection_pose_major_kernel_is_bitwise_the_row_major_pair(zh):
+    """From 8 192 poses up (J = 17, 16-byte aligned rows) errors and arg-min come from ONE pose-major pass (select17_kernel: 64 poses per
+    wave, ground truth staged once, hypotheses streamed one ahead).  Against the row-major pair (one-lane-per-row errors + lane-per-pose
+    arg-min, taken for an unaligned row pointer): every row's error, the per-pose minimum and the arg-min BIT FOR BIT - P1 and P2, a
+    shard that starts and ends inside a hypothesis, an odd pose count (every hypothesis' tile starts at another 4-byte alignment), NaN rows,
+    a ragged last pose tile."""
+    rng = np.random.default_rng(68)
+    N, H = 8219, 4
+    gt = dev(0.3 * rng.standard_normal((N, 17, 3)), torch.float64)
+    bits = lambda t: t.view(torch.int64) if t.dtype == torch.float64 else t
+    for off, B in ((0, N * H), (N + 777, 2 * N + 5)):
+        x = (0.3 * rng.standard_normal((B, 17, 3))).astype(np.float32)
+        x[11, 2, 0] = np.nan
+        x[B - 3] = np.nan
+        xa = dev(x)
+        buf = torch.empty(B * 51 + 1, dtype=torch.float32, device="cuda")
+        xb = buf[1:].view(B, 17, 3)
+        xb.copy_(xa)
+        assert xa.data_ptr() % 16 == 0 and xb.data_ptr() % 16 == 4
+        for p2 in (False, True):
+            a = zh.min_mpjpe(xa, gt, N, procrustes=p2, row_offset=off)
+            b = zh.min_mpjpe(xb, gt, N, procrustes=p2, row_offset=off)
+            for name, ta, tb in zip(("err", "best", "best_h"), a, b):
+                assert torch.equal(bits(ta), bits(tb)), (off, B, p2, name, int((bits(ta) != bits(tb)).sum()))
+            assert int(torch.isnan(a[0]).sum()) == 2 and int((a[2] < 0).sum()) == 0          # both shards hold at least one hypothesis of every pose
+
+
+def test_pose_min_lane_per_pose_kernel_follows_numpy(zh):
+    """From 8 192 poses up the arg-min over hypotheses runs one LANE per pose (coalesced reads of one hypothesis at a time) instead of one
+    wavefront per pose; same total order (np.amin / np.argmin incl. NaN, ties to the lower hypothesis), on a shard that starts and ends
+    inside a hypothesis, and with poses that hold no local hypothesis at all."""
+    rng = np.random.default_rng(67)
+    N, H = 8300, 5
+    e = rng.random((H, N))
+    e[2, 17] = np.nan; e[4, 17] = np.nan; e[1, 300] = e[3, 300] = e.min() / 2          # NaN wins (first NaN index); ties to the lower index
+    flat = e.reshape(-1)
+    for off, B in ((0, H * N), (N // 2 + 3, 3 * N + 11), (2 * N + 100, 200)):
+        best, idx = zh.pose_min(dev(flat[off:off + B], torch.float64), N, row_offset=off)
+        held = np.zeros((H * N,), bool); held[off:off + B] = True; held = held.reshape(H, N)
+        col = np.where(held, e, np.inf)
+        nan_any = np.isnan(col).any(0)
+        want_h = np.where(nan_any, np.argmax(np.isnan(col), 0), np.argmin(np.where(np.isnan(col), np.inf, col), 0))
+        none = ~held.any(0)
+        want_h = np.where(none, -1, want_h)
+        got_h, got = idx.cpu().numpy(), best.cpu().numpy()
+        assert np.array_equal(got_h, want_h)
+        ok = ~none & ~nan_any
+        assert np.array_equal(got[ok], col[want_h[ok], np.flatnonzero(ok)]) and np.isnan(got[nan_any & ~none]).all() and np.isinf(got[none]).all()
+
+
 @pytest.mark.parametrize("B", [1300, 2304, 4096, 5000, 7000, 8500, 10000, 16384, 18000, 22000])
 def test_score_network_every_launch_shape(zh, W, weights0, B):
     """Row counts that take each tile-selection branch of the dense layers - exact fp32: 32 / 64 / 128-row tiles chosen by the

@@ -72,6 +72,8 @@ def main():
             if f16_only and any("[f32" in t for t in failed):
                 ok = False
             rows.append((flag, what + (" [both modes]" if f16_only else " [f32 cells]"), failed, passed, dt))
+            with open(dst + ".partial", "a") as f:        # a run cut short by a time limit still leaves every finished row behind
+                f.write(f"-D{flag} | {rows[-1][1]} | {len(failed)} | {passed} | {dt:.0f}\n" + "".join(f"    RED {t}\n" for t in failed))
             ok &= len(failed) > 0
             print(f"{flag}: {len(failed)} red / {passed} green in {dt:.0f} s", flush=True)
     finally:

@@ -210,6 +210,67 @@ __global__ void pose_min_kernel(const double *__restrict__ err, int B, int N, lo
     best_h[n] = hi;
 }
 
+// Many poses (N >= POSE_MIN_LANE_N), J = 17, round 6: the errors of ALL local hypotheses of 64 consecutive poses and their arg-min in ONE
+// pass, pose-major.  One wave per 64 poses: the poses' ground truth is staged once (26 KB, coalesced) and stays in the LDS while the
+// wave walks its hypotheses in ascending order; the 64 rows of hypothesis h are 13 KB of contiguous pose tensor, fetched with 16-byte
+// loads into registers one hypothesis AHEAD of the arithmetic and dropped into the LDS behind it (a lane then reads its own row at an odd
+// word stride: conflict free).  Where the row-major pair of kernels reads the ground truth once per row (from the L2) and the errors a
+// second time for the arg-min, this reads the pose tensor once and nothing else.  Same row_error statements, same min_takes order: the
+// same bits (tests/test_hip_parity.py::test_selection_pose_major_kernel_is_bitwise_the_row_major_pair).
+constexpr int SEL_CHUNKS = (RE_ROWS * RE_D + 3) / 4 + 1;          // 16-byte chunks that cover 64 rows at any 4-byte alignment of their first element
+constexpr int SEL_T = (SEL_CHUNKS + RE_ROWS - 1) / RE_ROWS;       // per lane
+__global__ __launch_bounds__(RE_ROWS) void select17_kernel(const float *__restrict__ pred, const double *__restrict__ gt, int B, int N,
+                                                            long long row_offset, int procrustes, double *__restrict__ err,
+                                                            double *__restrict__ best, int *__restrict__ best_h) {
+    __shared__ double sg[RE_ROWS * RE_D];
+    __shared__ __attribute__((aligned(16))) float sp[SEL_CHUNKS * 4];
+    const int lane = threadIdx.x, n0 = blockIdx.x * RE_ROWS, n = n0 + lane;
+    const int poses = min(RE_ROWS, N - n0);
+    for (int q = lane; q < poses * RE_D; q += RE_ROWS) sg[q] = gt[(size_t)n0 * RE_D + q];
+    const long long total = (long long)B * RE_D;                   // floats of the local pose tensor
+    const long long h_first = row_offset / N, h_last = (row_offset + B - 1) / N;
+    // chunk c of hypothesis h: floats [a + 4 c, a + 4 c + 4) of the tensor, a = the first element of the tile rounded down to a multiple of 4
+    f32x4 nxt[SEL_T];
+    auto fetch = [&](long long h) {
+        const long long e0 = (h * N + n0 - row_offset) * RE_D, a = e0 & ~3LL;
+#pragma unroll
+        for (int t = 0; t < SEL_T; ++t) {
+            const int c = lane + t * RE_ROWS;
+            const long long lo = a + 4LL * c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c < SEL_CHUNKS) {
+                if (lo >= 0 && lo + 3 < total) v = *reinterpret_cast<const f32x4 *>(pred + lo);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (lo + e >= 0 && lo + e < total) v[e] = pred[lo + e];
+            }
+            nxt[t] = v;
+        }
+    };
+    auto drop = [&]() {
+#pragma unroll
+        for (int t = 0; t < SEL_T; ++t) {
+            const int c = lane + t * RE_ROWS;
+            if (c < SEL_CHUNKS) *reinterpret_cast<f32x4 *>(sp + 4 * c) = nxt[t];
+        }
+    };
+    double e_min = __builtin_huge_val();
+    int h_min = -1;
+    fetch(h_first);
+    for (long long h = h_first; h <= h_last; ++h) {
+        drop();                                                    // tile h: registers -> LDS (one wave: LDS operations execute in order)
+        if (h < h_last) fetch(h + 1);                              // tile h + 1 on its way while tile h is worked on
+        const long long loc = h * N + n - row_offset;
+        if (n < N && loc >= 0 && loc < B) {
+            const int shift = (int)(((h * N + n0 - row_offset) * RE_D) & 3LL);
+            const double e = row_error(sp + shift + lane * RE_D, sg + lane * RE_D, 17, procrustes);
+            err[loc] = e;
+            if (min_takes(e, (int)h, e_min, h_min)) { e_min = e; h_min = (int)h; }
+        }
+    }
+    if (n < N) { best[n] = (h_min >= 0) ? e_min : __builtin_huge_val(); best_h[n] = h_min; }
+}
+
 hipError_t launch_pose_min(const double *err, int B, int N, long long row_offset, double *best, int *best_h, hipStream_t st) {
     if (N >= POSE_MIN_LANE_N) hipLaunchKernelGGL(pose_min_kernel, dim3((N + 127) / 128), dim3(128), 0, st, err, B, N, row_offset, best, best_h);
     else hipLaunchKernelGGL(pose_min_wave_kernel, dim3((N + 3) / 4), dim3(256), 0, st, err, B, N, row_offset, best, best_h);
@@ -218,8 +279,13 @@ hipError_t launch_pose_min(const double *err, int B, int N, long long row_offset
 
 hipError_t launch_min_mpjpe(const float *pred, const double *gt, int B, int N, int J, long long row_offset,
                             int procrustes, double *err, double *best, int *best_h, hipStream_t st) {
-    // (the staged kernel fetches the pose tensor with 16-byte loads: a row pointer that is not 16-byte aligned takes the generic kernel)
-    if (J == 17 && (reinterpret_cast<uintptr_t>(pred) & 15) == 0)
+    // (the staged kernels fetch the pose tensor with 16-byte loads: a row pointer that is not 16-byte aligned takes the generic kernel)
+    const bool aligned = (reinterpret_cast<uintptr_t>(pred) & 15) == 0;
+    if (J == 17 && aligned && N >= POSE_MIN_LANE_N) {              // many poses: errors and arg-min in one pose-major pass
+        hipLaunchKernelGGL(select17_kernel, dim3((N + RE_ROWS - 1) / RE_ROWS), dim3(RE_ROWS), 0, st, pred, gt, B, N, row_offset, procrustes, err, best, best_h);
+        return hipGetLastError();
+    }
+    if (J == 17 && aligned)
         hipLaunchKernelGGL(row_error17_kernel, dim3((B + RE_ROWS - 1) / RE_ROWS), dim3(RE_ROWS), 0, st, pred, gt, B, N, row_offset, procrustes, err);
     else
         hipLaunchKernelGGL(row_error_kernel, dim3((B + 127) / 128), dim3(128), 0, st, pred, gt, B, N, J, row_offset, procrustes, err);
