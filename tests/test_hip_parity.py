@@ -525,16 +525,17 @@ def test_selection_staged_kernel_is_bitwise_the_lane_per_row_kernel(zh):
 
 
 def test_selection_pose_major_kernel_is_bitwise_the_row_major_pair(zh):
-    """From 8 192 poses up (J = 17, 16-byte aligned rows) errors and arg-min come from ONE pose-major pass (select17_kernel: 64 poses per
-    wave, ground truth staged once, hypotheses streamed one ahead).  Against the row-major pair (one-lane-per-row errors + lane-per-pose
-    arg-min, taken for an unaligned row pointer): every row's error, the per-pose minimum and the arg-min BIT FOR BIT - P1 and P2, a
-    shard that starts and ends inside a hypothesis, an odd pose count (every hypothesis' tile starts at another 4-byte alignment), NaN rows,
-    a ragged last pose tile."""
+    """From 8 192 poses up (J = 17, 16-byte aligned rows) the row errors are computed POSE-MAJOR (row_error17_pose_major_kernel: 64 poses
+    per wave, their ground truth staged once per chunk of hypotheses, the hypotheses' rows streamed one ahead) and the arg-min by the
+    lane-per-pose kernel.  Against the row-major generic kernel (one lane per row straight from memory, taken for an unaligned row
+    pointer): every row's error, the per-pose minimum and the arg-min BIT FOR BIT - P1 and P2, a shard that starts and ends inside a
+    hypothesis, an odd pose count (every hypothesis' tile starts at another 4-byte alignment), NaN rows, a ragged last pose tile, more
+    than one hypothesis chunk."""
     rng = np.random.default_rng(68)
-    N, H = 8219, 4
+    N, H = 8219, 5
     gt = dev(0.3 * rng.standard_normal((N, 17, 3)), torch.float64)
     bits = lambda t: t.view(torch.int64) if t.dtype == torch.float64 else t
-    for off, B in ((0, N * H), (N + 777, 2 * N + 5)):
+    for off, B in ((0, N * H), (N + 777, 3 * N + 5)):
         x = (0.3 * rng.standard_normal((B, 17, 3))).astype(np.float32)
         x[11, 2, 0] = np.nan
         x[B - 3] = np.nan

@@ -5,6 +5,8 @@
 // reads of one hypothesis' errors at a time).
 #include "zedo_internal.h"
 
+#include <algorithm>
+
 namespace zedo {
 
 // One-sided Jacobi on the 3x3 matrix M (columns rotated until orthogonal): M V = U diag(s).
@@ -210,25 +212,29 @@ __global__ void pose_min_kernel(const double *__restrict__ err, int B, int N, lo
     best_h[n] = hi;
 }
 
-// Many poses (N >= POSE_MIN_LANE_N), J = 17, round 6: the errors of ALL local hypotheses of 64 consecutive poses and their arg-min in ONE
-// pass, pose-major.  One wave per 64 poses: the poses' ground truth is staged once (26 KB, coalesced) and stays in the LDS while the
-// wave walks its hypotheses in ascending order; the 64 rows of hypothesis h are 13 KB of contiguous pose tensor, fetched with 16-byte
-// loads into registers one hypothesis AHEAD of the arithmetic and dropped into the LDS behind it (a lane then reads its own row at an odd
-// word stride: conflict free).  Where the row-major pair of kernels reads the ground truth once per row (from the L2) and the errors a
-// second time for the arg-min, this reads the pose tensor once and nothing else.  Same row_error statements, same min_takes order: the
-// same bits (tests/test_hip_parity.py::test_selection_pose_major_kernel_is_bitwise_the_row_major_pair).
+// Many poses (N >= POSE_MIN_LANE_N), J = 17, round 6: the row errors POSE-MAJOR.  One wave per (64 consecutive poses, chunk of the local
+// hypotheses): the poses' ground truth is staged once (26 KB, coalesced) and stays in the LDS while the wave walks its hypotheses in
+// ascending order; the 64 rows of hypothesis h are 13 KB of contiguous pose tensor, fetched with 16-byte loads into registers one
+// hypothesis AHEAD of the arithmetic and dropped into the LDS behind it (a lane then reads its own row at an odd word stride: conflict
+// free).  Where the row-major kernel reads a pose's ground truth once per ROW (from the L2), this reads it once per chunk.  The hypotheses
+// are cut into chunks only to have enough workgroups to balance over the chip (1 108 pose tiles alone are 1.08 rounds of 1 024 resident
+// waves: the second round would run 8 % full); the arg-min over hypotheses follows in pose_min_kernel (28 MB of errors, coalesced).
+// Same row_error statements as every other kernel of this file: the same bits
+// (tests/test_hip_parity.py::test_selection_pose_major_kernel_is_bitwise_the_row_major_pair).
 constexpr int SEL_CHUNKS = (RE_ROWS * RE_D + 3) / 4 + 1;          // 16-byte chunks that cover 64 rows at any 4-byte alignment of their first element
 constexpr int SEL_T = (SEL_CHUNKS + RE_ROWS - 1) / RE_ROWS;       // per lane
-__global__ __launch_bounds__(RE_ROWS) void select17_kernel(const float *__restrict__ pred, const double *__restrict__ gt, int B, int N,
-                                                            long long row_offset, int procrustes, double *__restrict__ err,
-                                                            double *__restrict__ best, int *__restrict__ best_h) {
+__global__ __launch_bounds__(RE_ROWS) void row_error17_pose_major_kernel(const float *__restrict__ pred, const double *__restrict__ gt, int B, int N,
+                                                                          long long row_offset, int procrustes, int h_per_chunk,
+                                                                          double *__restrict__ err) {
     __shared__ double sg[RE_ROWS * RE_D];
     __shared__ __attribute__((aligned(16))) float sp[SEL_CHUNKS * 4];
     const int lane = threadIdx.x, n0 = blockIdx.x * RE_ROWS, n = n0 + lane;
     const int poses = min(RE_ROWS, N - n0);
-    for (int q = lane; q < poses * RE_D; q += RE_ROWS) sg[q] = gt[(size_t)n0 * RE_D + q];
     const long long total = (long long)B * RE_D;                   // floats of the local pose tensor
-    const long long h_first = row_offset / N, h_last = (row_offset + B - 1) / N;
+    const long long h_lo = row_offset / N + (long long)blockIdx.y * h_per_chunk;
+    const long long h_hi = min((row_offset + B - 1) / N, h_lo + h_per_chunk - 1);
+    if (h_lo > h_hi) return;
+    for (int q = lane; q < poses * RE_D; q += RE_ROWS) sg[q] = gt[(size_t)n0 * RE_D + q];
     // chunk c of hypothesis h: floats [a + 4 c, a + 4 c + 4) of the tensor, a = the first element of the tile rounded down to a multiple of 4
     f32x4 nxt[SEL_T];
     auto fetch = [&](long long h) {
@@ -254,21 +260,16 @@ __global__ __launch_bounds__(RE_ROWS) void select17_kernel(const float *__restri
             if (c < SEL_CHUNKS) *reinterpret_cast<f32x4 *>(sp + 4 * c) = nxt[t];
         }
     };
-    double e_min = __builtin_huge_val();
-    int h_min = -1;
-    fetch(h_first);
-    for (long long h = h_first; h <= h_last; ++h) {
+    fetch(h_lo);
+    for (long long h = h_lo; h <= h_hi; ++h) {
         drop();                                                    // tile h: registers -> LDS (one wave: LDS operations execute in order)
-        if (h < h_last) fetch(h + 1);                              // tile h + 1 on its way while tile h is worked on
+        if (h < h_hi) fetch(h + 1);                                // tile h + 1 on its way while tile h is worked on
         const long long loc = h * N + n - row_offset;
         if (n < N && loc >= 0 && loc < B) {
             const int shift = (int)(((h * N + n0 - row_offset) * RE_D) & 3LL);
-            const double e = row_error(sp + shift + lane * RE_D, sg + lane * RE_D, 17, procrustes);
-            err[loc] = e;
-            if (min_takes(e, (int)h, e_min, h_min)) { e_min = e; h_min = (int)h; }
+            err[loc] = row_error(sp + shift + lane * RE_D, sg + lane * RE_D, 17, procrustes);
         }
     }
-    if (n < N) { best[n] = (h_min >= 0) ? e_min : __builtin_huge_val(); best_h[n] = h_min; }
 }
 
 hipError_t launch_pose_min(const double *err, int B, int N, long long row_offset, double *best, int *best_h, hipStream_t st) {
@@ -281,10 +282,16 @@ hipError_t launch_min_mpjpe(const float *pred, const double *gt, int B, int N, i
                             int procrustes, double *err, double *best, int *best_h, hipStream_t st) {
     // (the staged kernels fetch the pose tensor with 16-byte loads: a row pointer that is not 16-byte aligned takes the generic kernel)
     const bool aligned = (reinterpret_cast<uintptr_t>(pred) & 15) == 0;
-    if (J == 17 && aligned && N >= POSE_MIN_LANE_N) {              // many poses: errors and arg-min in one pose-major pass
-        hipLaunchKernelGGL(select17_kernel, dim3((N + RE_ROWS - 1) / RE_ROWS), dim3(RE_ROWS), 0, st, pred, gt, B, N, row_offset, procrustes, err, best, best_h);
-        return hipGetLastError();
-    }
+    if (J == 17 && aligned && N >= POSE_MIN_LANE_N) {              // many poses: the row errors pose-major
+        const int tiles = (N + RE_ROWS - 1) / RE_ROWS;
+        const long long h_local = (row_offset + B - 1) / N - row_offset / N + 1;              // hypotheses this shard touches
+        // enough workgroups for ~8 rounds of the resident waves (4 per CU: 39 KB of LDS each), at least 2 hypotheses per chunk
+        long long chunks = (8LL * 4 * num_cus() + tiles - 1) / tiles;
+        chunks = std::max(1LL, std::min(chunks, (h_local + 1) / 2));
+        const int per = (int)((h_local + chunks - 1) / chunks);
+        chunks = (h_local + per - 1) / per;
+        hipLaunchKernelGGL(row_error17_pose_major_kernel, dim3(tiles, (unsigned)chunks), dim3(RE_ROWS), 0, st, pred, gt, B, N, row_offset, procrustes, per, err);
+    } else
     if (J == 17 && aligned)
         hipLaunchKernelGGL(row_error17_kernel, dim3((B + RE_ROWS - 1) / RE_ROWS), dim3(RE_ROWS), 0, st, pred, gt, B, N, row_offset, procrustes, err);
     else
