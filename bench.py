@@ -92,22 +92,24 @@ def cpu_baseline(weights, cfg_kw, seed):
     x_init = torch.tensor(np.einsum("bij,bkj->bki", R, x0).astype(np.float32))
     T_init = torch.tensor(T.astype(np.float32))
     ts = O.oil_timestamps(S_OIL)
-    # thread count: more is not faster for [1015 x 1024] operands (256 threads: 5.8 s per step on the GPU box);
-    # double from 8 while a step gets faster, keep the best
+    # thread count: more is not faster for [1015 x 1024] operands (EPYC 9575F hosts of the pool: 32 threads ~90 ms per step, 64 ~150 ms,
+    # 128 ~400 ms, 256: 5.8 s) and single probes are noisy on a shared host: every candidate runs a 12-step slice, the MEDIAN step decides
     x, Tt = x_init, T_init
-    cores, best = 1, float("inf")
-    for th in [c for c in (8, 16, 32, 64, 128, 256) if c <= avail] or [avail]:
+    cores, best, probes = 1, float("inf"), {}
+    for th in [c for c in (8, 16, 32, 64, 128) if c <= avail] or [avail]:
         torch.set_num_threads(th)
         for i in range(2):
             port.step(x, Tt, ts[0], False)              # warm the pool at this size
-        dt = float("inf")
-        for i in range(4):                              # the fastest of four steps: one slow step must not pick the count
+        dts = []
+        for i in range(12):
             t0 = time.perf_counter()
-            port.step(x, Tt, ts[i], True)
-            dt = min(dt, time.perf_counter() - t0)
+            port.step(x, Tt, ts[i], i >= 3)
+            dts.append(time.perf_counter() - t0)
+        dt = float(np.median(dts))
+        probes[th] = round(dt * 1e3, 1)
         if dt < best:
             cores, best = th, dt
-        if dt > 1.5 * best:
+        if dt > 2.0 * best:
             break
 
     def oil_slice(nsteps):       # the first 1/5 with the IPO's T, the rest with the least-squares T, like the loop itself
@@ -131,7 +133,7 @@ def cpu_baseline(weights, cfg_kw, seed):
     per_pose_hyp = (t_ipo + S_OIL * t_step + t_eval) / n
     per_pose_hyp_1t = (t_ipo + S_OIL * t_step_1t + t_eval) / n
     return dict(value=1.0 / (N_HYPO * per_pose_hyp), unit="poses/s", cores=int(cores), kind="port",
-                cpu_model=cpu_model_name(), threads_available=int(avail),
+                cpu_model=cpu_model_name(), threads_available=int(avail), thread_count_probe_ms_per_step=probes,
                 one_thread=dict(value=1.0 / (N_HYPO * per_pose_hyp_1t), unit="poses/s", cores=1,
                                 ms_per_step=round(t_step_1t * 1e3, 1), steps_timed=steps_1t),
                 ms_per_step=round(t_step * 1e3, 2), steps_timed=steps, ipo_s=round(t_ipo, 2), metric_s=round(t_eval, 2),
