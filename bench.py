@@ -92,8 +92,9 @@ def cpu_baseline(weights, cfg_kw, seed):
     x_init = torch.tensor(np.einsum("bij,bkj->bki", R, x0).astype(np.float32))
     T_init = torch.tensor(T.astype(np.float32))
     ts = O.oil_timestamps(S_OIL)
-    # thread count: more is not faster for [1015 x 1024] operands (EPYC 9575F hosts of the pool: 32 threads ~90 ms per step, 64 ~150 ms,
-    # 128 ~400 ms, 256: 5.8 s) and single probes are noisy on a shared host: every candidate runs a 12-step slice, the MEDIAN step decides
+    # thread count: more is not faster for [1015 x 1024] operands, and the GPU boxes' hosts are SHARED (load average 30-70 of 256 threads from other
+    # tenants: at 64 threads a step takes 13 ms or 80 ms from one call to the next, at 16-32 threads 12-15 ms with a 25 ms mean; 128: 200 ms):
+    # every candidate runs a 12-step slice and its MEAN step (what the reported slice will be made of) decides
     x, Tt = x_init, T_init
     cores, best, probes = 1, float("inf"), {}
     for th in [c for c in (8, 16, 32, 64, 128) if c <= avail] or [avail]:
@@ -105,7 +106,7 @@ def cpu_baseline(weights, cfg_kw, seed):
             t0 = time.perf_counter()
             port.step(x, Tt, ts[i], i >= 3)
             dts.append(time.perf_counter() - t0)
-        dt = float(np.median(dts))
+        dt = float(np.mean(dts))
         probes[th] = round(dt * 1e3, 1)
         if dt < best:
             cores, best = th, dt
@@ -134,6 +135,7 @@ def cpu_baseline(weights, cfg_kw, seed):
     per_pose_hyp_1t = (t_ipo + S_OIL * t_step_1t + t_eval) / n
     return dict(value=1.0 / (N_HYPO * per_pose_hyp), unit="poses/s", cores=int(cores), kind="port",
                 cpu_model=cpu_model_name(), threads_available=int(avail), thread_count_probe_ms_per_step=probes,
+                host_load_average=[round(v, 1) for v in os.getloadavg()],      # the hosts are shared: this baseline moves with the neighbours' load
                 one_thread=dict(value=1.0 / (N_HYPO * per_pose_hyp_1t), unit="poses/s", cores=1,
                                 ms_per_step=round(t_step_1t * 1e3, 1), steps_timed=steps_1t),
                 ms_per_step=round(t_step * 1e3, 2), steps_timed=steps, ipo_s=round(t_ipo, 2), metric_s=round(t_eval, 2),
