@@ -79,7 +79,7 @@ def test_bench_exchange_step_on_rccl_is_bit_identical():
         assert sc[kind]["ok"] and sc[kind]["sha"] == sc[kind]["sha_unsharded"] and len(sc[kind]["sha"]) == 16
     st = b["strong"]
     assert st["scaling"] == "strong" and st["n_gpus"] == 1 and st["matches_one_rank"] and st["selection_sha16"] == st["one_rank_selection_sha16"]
-    assert st["ms_per_step"] > 0 and st["one_rank"]["ms_per_step"] > 0 and 0.5 < st["speedup_vs_one_rank"] < 1.5
+    assert st["ms_per_step"] > 0 and st["one_rank"]["ms_per_step"] > 0 and 0.2 < st["speedup_vs_one_rank"] < 5.0      # one rank against itself on a ~10 ms problem: a sanity check, not a measurement
     assert st["alt_mode"]["math"] == "f16x3" and st["alt_mode"]["matches_one_rank"]
 
 
