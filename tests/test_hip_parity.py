@@ -371,7 +371,10 @@ def test_ipo_kernels_are_bitwise_twins():
 
 
 
-@pytest.mark.parametrize("N,axes,kname", IPO_CASES)
+IPO_CUSTOM = [(N, axes, kname) for N in (8, 64) for axes in ("z", "xyz") for kname in ("k1", "k5", "k8", "k12")]
+
+
+@pytest.mark.parametrize("N,axes,kname", IPO_CASES + IPO_CUSTOM)
 def test_ipo_single_iterations_from_reference_state(zh, golden, N, axes, kname):
     """Every one of the first 50 Adam iterations, taken on its own from the REFERENCE's optimiser state.
 
@@ -384,8 +387,15 @@ def test_ipo_single_iterations_from_reference_state(zh, golden, N, axes, kname):
     sign-unambiguous (|e| >= 1e-3 px; the root joint sits on the ray through the origin and contributes no gradient,
     it is not counted).  Ambiguous (pose, iteration) pairs are counted and reported, not compared."""
     import zedo_oracle as O
-    g = golden("ipo")
-    kl, ipoT, minT = ([0, 1, 4], 3.0, 0.5) if kname == "h36m" else (list(range(17)), 8.0, 0.2)
+    # round 6: also for key lists the shipped configurations do not use (1, 5, 8, 12 joints: tests/golden/ipo_custom.npz,
+    # tools/gen_golden.py::gen_ipo_custom) - every key-list length has its own lane-per-row instantiation since this round
+    if kname in ("h36m", "pw3d"):
+        g = golden("ipo")
+        kl, ipoT, minT = ([0, 1, 4], 3.0, 0.5) if kname == "h36m" else (list(range(17)), 8.0, 0.2)
+    else:
+        g = golden("ipo_custom")
+        kl = [int(k) for k in g[f"keylist_{kname}"]]
+        ipoT, minT = (3.0, 0.5) if kname in ("k1", "k5") else (8.0, 0.2)
     tag = f"{N}_{axes}_{kname}"
     cond, Kn = g[f"db2d_{N}"][:, :, :2], g[f"K_{N}"]
     uv, K, x0 = dev(cond), dev(Kn), dev(g["cluster0"][None])

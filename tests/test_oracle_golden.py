@@ -127,6 +127,36 @@ def test_ipo_hand_derived_gradients_follow_autograd(golden, N, axes, kname):
     assert np.allclose(np.einsum("bij,bkj->bik", R, R), np.eye(3)[None], atol=1e-5)
 
 
+IPO_CUSTOM = [(N, axes, kname) for N in (8, 64) for axes in ("z", "xyz") for kname in ("k1", "k5", "k8", "k12")]
+
+
+@pytest.mark.parametrize("N,axes,kname", IPO_CUSTOM)
+def test_ipo_custom_key_lists_follow_the_reference(golden, N, axes, kname):
+    """Key lists the shipped configurations do not use (ZeDO.IPO_keylist is a config value: 1, 5, 8, 12 joints, with and without the root
+    joint; tools/gen_golden.py::gen_ipo_custom runs the reference's loop, opt_main.py:170-195): the float64 oracle reproduces the
+    reference's float64 run over all 50 traced iterations to 1e-8 (it is the arbiter of the GPU per-iteration test), the fp32 oracle the
+    reference's first fp32 iteration to 1e-6 and its end-state loss after 500 iterations to 5 %."""
+    g = golden("ipo_custom")
+    kl = [int(k) for k in g[f"keylist_{kname}"]]
+    ipoT, minT = (3.0, 0.5) if kname in ("k1", "k5") else (8.0, 0.2)
+    tag = f"{N}_{axes}_{kname}"
+    cond, K = g[f"db2d_{N}"][:, :, :2], g[f"K_{N}"]
+    x0 = np.broadcast_to(g["cluster0"][None], (N, 17, 3))
+    c64, K64, x64 = cond.astype(np.float64), K.astype(np.float64), x0.astype(np.float64)
+    tr = []
+    O.ipo_fit(x64[:, kl], O.ipo_init_T(c64, K64, ipoT, dtype=np.float64), K64, c64[:, kl], axes, minT, 2.0, 50, dtype=np.float64, trace=tr)
+    for it in range(50):
+        assert np.abs(tr[it][0] - g[f"trace_q64_{tag}"][it]).max() <= 1e-8, it
+        assert np.abs(tr[it][1] - g[f"trace_scale64_{tag}"][it].reshape(-1)).max() <= 1e-8, it
+        assert abs(tr[it][2] - g[f"trace_loss64_{tag}"][it]) <= 1e-9 * max(1.0, g[f"trace_loss64_{tag}"][it])
+    tr32 = []
+    x32 = x0.astype(np.float32)
+    R, T, q, s, loss = O.ipo_fit(x32[:, kl], O.ipo_init_T(cond, K, ipoT), K, cond[:, kl], axes, minT, 2.0, 500, trace=tr32)
+    np.testing.assert_allclose(tr32[0][0], g[f"trace_q1_{tag}"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(tr32[0][1], g[f"trace_scale1_{tag}"].reshape(-1), atol=1e-6, rtol=0)
+    assert abs(loss - g[f"loss_{tag}"]) <= 0.05 * g[f"loss_{tag}"] + 1e-3
+
+
 @pytest.mark.parametrize("S", [100, 1000])
 def test_oil_loop_snapshots(golden, weights0, S):
     g = golden("oil")

@@ -286,6 +286,39 @@ def gen_ipo():
     save("ipo", cluster0=centred[0], **out)
 
 
+# custom ZeDO.IPO_keylist values (config-reachable; round 6: every key-list length has its lane-per-row kernel): key lists of 1, 5, 8 and 12
+# joints, with and without the root joint
+IPO_CUSTOM_KEYLISTS = dict(k1=([4], 3.0, 0.5), k5=([0, 2, 5, 11, 14], 3.0, 0.5), k8=([0, 1, 4, 7, 8, 11, 14, 16], 8.0, 0.2),
+                           k12=(list(range(1, 13)), 8.0, 0.2))
+
+
+def gen_ipo_custom():
+    """The reference's IPO loop (opt_main.py:170-195) in float64 - the arbiter of the per-iteration parity test - for key lists the shipped
+    configurations do not use, on the problems of gen_ipo (same clusters, poses, intrinsics), plus the fp32 end state after 500 iterations.
+    A file of its own: tests/golden/ipo.npz stays byte for byte what round 1-5 generated."""
+    out = {}
+    clusters = syn.make_clusters(2, seed=5)
+    centred = clusters - clusters[:, 0:1]
+    for N in (8, 64):
+        d = syn.make_poses(N, seed=11 + N)
+        out[f"db2d_{N}"] = d["db_2d"]
+        out[f"K_{N}"] = d["camera_param"]
+        x0 = np.broadcast_to(centred[0][None], (N, 17, 3)).astype(np.float32).copy()
+        for axes in ("z", "xyz"):
+            for kname, (kl, ipoT, minT) in IPO_CUSTOM_KEYLISTS.items():
+                r64 = run_ref_ipo(x0, d["db_2d"][:, :, :2], d["camera_param"], axes, kl, ipoT, minT, 2.0, IPO_TRACE,
+                                  trace_upto=IPO_TRACE, dtype=torch.float64)
+                out[f"trace_q64_{N}_{axes}_{kname}"] = r64["trace_q"]
+                out[f"trace_scale64_{N}_{axes}_{kname}"] = r64["trace_scale"]
+                out[f"trace_loss64_{N}_{axes}_{kname}"] = r64["trace_loss"]
+                r32 = run_ref_ipo(x0, d["db_2d"][:, :, :2], d["camera_param"], axes, kl, ipoT, minT, 2.0, 500, trace_upto=1)
+                out[f"loss_{N}_{axes}_{kname}"] = r32["loss"]
+                out[f"trace_q1_{N}_{axes}_{kname}"] = r32["trace_q"][0]
+                out[f"trace_scale1_{N}_{axes}_{kname}"] = r32["trace_scale"][0]
+                out[f"keylist_{kname}"] = np.array(kl, np.int32)
+    save("ipo_custom", cluster0=centred[0], **out)
+
+
 def run_ref_oil(m, x, cond, conf, K, T, S, snaps, dtype=torch.float32):
     """opt_main.py:197-222 (the torch.no_grad block), CPU tensors."""
     fn = ref_sampling_fn(x.shape[0])
@@ -1118,7 +1151,7 @@ def gen_driver_pw3d_full_c_oil64():
 
 
 
-GENS = dict(model=gen_model, weights_alt=gen_weights_alt, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo, oil=gen_oil,
+GENS = dict(model=gen_model, weights_alt=gen_weights_alt, pc_step=gen_pc_step, reproj=gen_reproj, ipo=gen_ipo, ipo_custom=gen_ipo_custom, oil=gen_oil,
             eval=gen_eval, driver=gen_driver, datasets=gen_datasets,
             driver_files=gen_driver_files, samplers=gen_samplers, pc_generic=gen_pc_generic, hp3d_ski=gen_3dhp_ski, driver_full=gen_driver_full,
             driver_h36m_full=gen_driver_h36m_full, driver_pw3d_full=gen_driver_pw3d_full,
